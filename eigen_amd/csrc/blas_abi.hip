@@ -1,0 +1,307 @@
+// C ABI of libeigen_amd_blas.so (declarations: include/eigen_amd_blas.h).
+//
+// The F77 entry points restate the argument handling of EIGEN_BLAS_FUNC(gemm)
+// (blas/level3_impl.h:47-69 of the Eigen tree) and hand the product itself to
+// the MFMA kernels; there is no CPU compute path in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "../../include/eigen_amd_blas.h"
+#include "gemm_launch.hpp"
+#include "rng.hpp"
+
+using namespace eigamd;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& what) {
+  g_err = what;
+  return code;
+}
+int hip_fail(hipError_t e, const char* where) {
+  return fail(EIGAMD_ERR_DEVICE, std::string(where) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                   \
+  do {                                                  \
+    hipError_t e_ = (expr);                             \
+    if (e_ != hipSuccess) return hip_fail(e_, #expr);   \
+  } while (0)
+
+constexpr int kElemSize[4] = {4, 8, 8, 16};
+
+hipError_t launch(const GemmCall& c, hipStream_t s) {
+  switch (c.kind) {
+    case F32: return launch_gemm_f32(c, s);
+    case F64: return launch_gemm_f64(c, s);
+    case C32: return launch_gemm_c32(c, s);
+    case C64: return launch_gemm_c64(c, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+void read_scalar(int dtype, const void* p, double out[2]) {
+  switch (dtype) {
+    case F32: out[0] = *static_cast<const float*>(p); out[1] = 0; break;
+    case F64: out[0] = *static_cast<const double*>(p); out[1] = 0; break;
+    case C32: out[0] = static_cast<const float*>(p)[0]; out[1] = static_cast<const float*>(p)[1]; break;
+    default:  out[0] = static_cast<const double*>(p)[0]; out[1] = static_cast<const double*>(p)[1]; break;
+  }
+}
+
+bool stored_rows_is_m(int op) { return op == OP_N || op == OP_CONJ; }
+
+// Argument checks shared by the 64-bit entry points; the order and the codes
+// are those of blas/level3_impl.h:47-55.
+int check_args(int opa, int opb, int64_t m, int64_t n, int64_t k, int64_t lda, int64_t ldb,
+               int64_t ldc) {
+  if (opa < 0 || opa > 3) return 1;
+  if (opb < 0 || opb > 3) return 2;
+  if (m < 0) return 3;
+  if (n < 0) return 4;
+  if (k < 0) return 5;
+  if (lda < std::max<int64_t>(1, stored_rows_is_m(opa) ? m : k)) return 8;
+  if (ldb < std::max<int64_t>(1, stored_rows_is_m(opb) ? k : n)) return 10;
+  if (ldc < std::max<int64_t>(1, m)) return 13;
+  return 0;
+}
+
+int ensure_device() {
+  static int state = 0;  // 0 unknown, 1 ok, -1 none
+  if (state == 0) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+      state = -1;
+    } else {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+          std::strncmp(prop.gcnArchName, "gfx950", 6) == 0)
+        state = 1;
+      else
+        state = -1;
+    }
+  }
+  if (state < 0) return fail(EIGAMD_ERR_NO_GPU, "no gfx950 (MI355X) device is visible; this library has no CPU path");
+  return EIGAMD_OK;
+}
+
+// Device staging buffers for host-pointer calls: grow-only, owned by the
+// process, guarded by one mutex (callers may invoke ?gemm_ from several host
+// threads; the reference entry points are re-entrant).
+struct Staging {
+  std::mutex mu;
+  void* buf[3] = {nullptr, nullptr, nullptr};
+  size_t cap[3] = {0, 0, 0};
+  hipStream_t stream = nullptr;
+  int reserve(int i, size_t bytes) {
+    if (bytes <= cap[i]) return EIGAMD_OK;
+    if (buf[i]) { HIP_TRY(hipFree(buf[i])); buf[i] = nullptr; cap[i] = 0; }
+    size_t want = bytes + bytes / 4 + 4096;
+    HIP_TRY(hipMalloc(&buf[i], want));
+    cap[i] = want;
+    return EIGAMD_OK;
+  }
+};
+Staging& staging() {
+  static Staging s;
+  return s;
+}
+
+int64_t round_up(int64_t v, int64_t q) { return (v + q - 1) / q * q; }
+
+int gemm_host_impl(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k,
+                   const double alpha[2], const void* a, int64_t lda, const void* b, int64_t ldb,
+                   const double beta[2], void* c, int64_t ldc) {
+  if (m == 0 || n == 0) return EIGAMD_OK;                          // level3_impl.h:59-60
+  const bool beta_is_one = beta[0] == 1.0 && beta[1] == 0.0;
+  if (k == 0 && beta_is_one) return EIGAMD_OK;                     // level3_impl.h:62-69
+  int rc = ensure_device();
+  if (rc != EIGAMD_OK) return rc;
+
+  const int es = kElemSize[dtype];
+  const int64_t a_rows = stored_rows_is_m(opa) ? m : k, a_cols = stored_rows_is_m(opa) ? k : m;
+  const int64_t b_rows = stored_rows_is_m(opb) ? k : n, b_cols = stored_rows_is_m(opb) ? n : k;
+  // Device leading dimensions: 16-byte aligned rows so the vector kernels apply.
+  const int64_t dlda = round_up(std::max<int64_t>(a_rows, 1), 16);
+  const int64_t dldb = round_up(std::max<int64_t>(b_rows, 1), 16);
+  const int64_t dldc = round_up(m, 16);
+  const bool beta_is_zero = beta[0] == 0.0 && beta[1] == 0.0;
+
+  Staging& st = staging();
+  std::lock_guard<std::mutex> lock(st.mu);
+  if (!st.stream) HIP_TRY(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
+  if (k > 0) {
+    if ((rc = st.reserve(0, (size_t)dlda * a_cols * es)) != EIGAMD_OK) return rc;
+    if ((rc = st.reserve(1, (size_t)dldb * b_cols * es)) != EIGAMD_OK) return rc;
+  }
+  if ((rc = st.reserve(2, (size_t)dldc * n * es)) != EIGAMD_OK) return rc;
+
+  if (k > 0) {
+    HIP_TRY(hipMemcpy2DAsync(st.buf[0], dlda * es, a, lda * es, a_rows * es, a_cols,
+                             hipMemcpyHostToDevice, st.stream));
+    HIP_TRY(hipMemcpy2DAsync(st.buf[1], dldb * es, b, ldb * es, b_rows * es, b_cols,
+                             hipMemcpyHostToDevice, st.stream));
+  }
+  if (!beta_is_zero)
+    HIP_TRY(hipMemcpy2DAsync(st.buf[2], dldc * es, c, ldc * es, m * es, n, hipMemcpyHostToDevice,
+                             st.stream));
+  GemmCall call;
+  call.kind = dtype; call.opa = opa; call.opb = opb;
+  call.m = m; call.n = n; call.k = k;
+  call.alpha[0] = alpha[0]; call.alpha[1] = alpha[1];
+  call.beta[0] = beta[0]; call.beta[1] = beta[1];
+  call.A = st.buf[0]; call.lda = dlda;
+  call.B = st.buf[1]; call.ldb = dldb;
+  call.C = st.buf[2]; call.ldc = dldc;
+  HIP_TRY(launch(call, st.stream));
+  // Only the m x n window goes back: rows m..ldc-1 of C keep the caller's bytes.
+  HIP_TRY(hipMemcpy2DAsync(c, ldc * es, st.buf[2], dldc * es, m * es, n, hipMemcpyDeviceToHost,
+                           st.stream));
+  HIP_TRY(hipStreamSynchronize(st.stream));
+  return EIGAMD_OK;
+}
+
+int op_of(char ch) {  // blas/common.h:47-50
+  switch (ch) {
+    case 'N': case 'n': return OP_N;
+    case 'T': case 't': return OP_T;
+    case 'C': case 'c': return OP_C;
+  }
+  return -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+// The process's xerbla_ wins when one is linked in (the Netlib testers install
+// their own); this weak default prints like blas/xerbla.cpp:15-19.
+__attribute__((weak)) int xerbla_(const char* msg, int* info, int) {
+  std::printf("Eigen BLAS ERROR #%i: %s\n", *info, msg);
+  return 0;
+}
+
+static int f77_gemm(int dtype, const char* name, const char* transa, const char* transb,
+                    const int* m, const int* n, const int* k, const void* alpha, const void* a,
+                    const int* lda, const void* b, const int* ldb, const void* beta, void* c,
+                    const int* ldc) {
+  const int opa = op_of(*transa), opb = op_of(*transb);
+  int info = 0;
+  if (opa < 0) info = 1;
+  else if (opb < 0) info = 2;
+  else info = check_args(opa, opb, *m, *n, *k, *lda, *ldb, *ldc);
+  if (info) return xerbla_(name, &info, 6);
+  double al[2], be[2];
+  read_scalar(dtype, alpha, al);
+  read_scalar(dtype, beta, be);
+  int rc = gemm_host_impl(dtype, opa, opb, *m, *n, *k, al, a, *lda, b, *ldb, be, c, *ldc);
+  if (rc != EIGAMD_OK) {
+    // The F77 ABI has no error channel besides xerbla_; a device failure must not
+    // pass silently as a computed product.
+    std::fprintf(stderr, "eigen_amd %s: %s\n", name, g_err.c_str());
+    std::abort();
+  }
+  return 0;
+}
+
+int sgemm_(const char* ta, const char* tb, const int* m, const int* n, const int* k,
+           const float* alpha, const float* a, const int* lda, const float* b, const int* ldb,
+           const float* beta, float* c, const int* ldc) {
+  return f77_gemm(F32, "SGEMM ", ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc);
+}
+int dgemm_(const char* ta, const char* tb, const int* m, const int* n, const int* k,
+           const double* alpha, const double* a, const int* lda, const double* b, const int* ldb,
+           const double* beta, double* c, const int* ldc) {
+  return f77_gemm(F64, "DGEMM ", ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc);
+}
+int cgemm_(const char* ta, const char* tb, const int* m, const int* n, const int* k,
+           const float* alpha, const float* a, const int* lda, const float* b, const int* ldb,
+           const float* beta, float* c, const int* ldc) {
+  return f77_gemm(C32, "CGEMM ", ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc);
+}
+int zgemm_(const char* ta, const char* tb, const int* m, const int* n, const int* k,
+           const double* alpha, const double* a, const int* lda, const double* b, const int* ldb,
+           const double* beta, double* c, const int* ldc) {
+  return f77_gemm(C64, "ZGEMM ", ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc);
+}
+
+int eigamd_gemm_host(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k,
+                     const void* alpha, const void* a, int64_t lda, const void* b, int64_t ldb,
+                     const void* beta, void* c, int64_t ldc) {
+  if (dtype < 0 || dtype > 3) return fail(EIGAMD_ERR_ARG, "dtype out of range");
+  const int info = check_args(opa, opb, m, n, k, lda, ldb, ldc);
+  if (info) return fail(EIGAMD_ERR_ARG, "invalid argument #" + std::to_string(info));
+  if (m > 0x7fffffff || n > 0x7fffffff || k > 0x7fffffff)
+    return fail(EIGAMD_ERR_ARG, "extent exceeds 2^31-1");
+  double al[2], be[2];
+  read_scalar(dtype, alpha, al);
+  read_scalar(dtype, beta, be);
+  return gemm_host_impl(dtype, opa, opb, m, n, k, al, a, lda, b, ldb, be, c, ldc);
+}
+
+int eigamd_gemm_dev(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k,
+                    const void* alpha, const void* d_a, int64_t lda, const void* d_b,
+                    int64_t ldb, const void* beta, void* d_c, int64_t ldc, void* stream) {
+  if (dtype < 0 || dtype > 3) return fail(EIGAMD_ERR_ARG, "dtype out of range");
+  const int info = check_args(opa, opb, m, n, k, lda, ldb, ldc);
+  if (info) return fail(EIGAMD_ERR_ARG, "invalid argument #" + std::to_string(info));
+  if (m > 0x7fffffff || n > 0x7fffffff || k > 0x7fffffff)
+    return fail(EIGAMD_ERR_ARG, "extent exceeds 2^31-1");
+  if (m == 0 || n == 0) return EIGAMD_OK;
+  int rc = ensure_device();
+  if (rc != EIGAMD_OK) return rc;
+  GemmCall call;
+  call.kind = dtype; call.opa = opa; call.opb = opb;
+  call.m = m; call.n = n; call.k = k;
+  read_scalar(dtype, alpha, call.alpha);
+  read_scalar(dtype, beta, call.beta);
+  if (k == 0 && call.beta[0] == 1.0 && call.beta[1] == 0.0) return EIGAMD_OK;
+  call.A = d_a; call.lda = lda;
+  call.B = d_b; call.ldb = ldb;
+  call.C = d_c; call.ldc = ldc;
+  HIP_TRY(launch(call, static_cast<hipStream_t>(stream)));
+  return EIGAMD_OK;
+}
+
+int eigamd_fill_uniform_dev(int dtype, void* d_x, int64_t rows, int64_t cols, int64_t ld,
+                            uint64_t seed, void* stream) {
+  if (dtype < 0 || dtype > 3 || rows < 0 || cols < 0 || ld < std::max<int64_t>(rows, 1))
+    return fail(EIGAMD_ERR_ARG, "invalid fill arguments");
+  if (rows == 0 || cols == 0) return EIGAMD_OK;
+  int rc = ensure_device();
+  if (rc != EIGAMD_OK) return rc;
+  HIP_TRY(fill_uniform_device(dtype, d_x, rows, cols, ld, seed, static_cast<hipStream_t>(stream)));
+  return EIGAMD_OK;
+}
+
+int eigamd_fill_uniform_host(int dtype, void* x, int64_t rows, int64_t cols, int64_t ld,
+                             uint64_t seed) {
+  if (dtype < 0 || dtype > 3 || rows < 0 || cols < 0 || ld < std::max<int64_t>(rows, 1))
+    return fail(EIGAMD_ERR_ARG, "invalid fill arguments");
+  fill_uniform_host(dtype, x, rows, cols, ld, seed);
+  return EIGAMD_OK;
+}
+
+const char* eigamd_last_error(void) { return g_err.c_str(); }
+
+int eigamd_device_ok(void) { return ensure_device() == EIGAMD_OK ? 1 : 0; }
+
+void eigamd_tile_shape(int dtype, int* bm, int* bn, int* bk) {
+  switch (dtype) {
+    case F32: *bm = Geometry<F32>::BM; *bn = Geometry<F32>::BN; *bk = Geometry<F32>::BK; break;
+    case F64: *bm = Geometry<F64>::BM; *bn = Geometry<F64>::BN; *bk = Geometry<F64>::BK; break;
+    case C32: *bm = Geometry<C32>::BM; *bn = Geometry<C32>::BN; *bk = Geometry<C32>::BK; break;
+    default:  *bm = Geometry<C64>::BM; *bn = Geometry<C64>::BN; *bk = Geometry<C64>::BK; break;
+  }
+}
+
+}  // extern "C"

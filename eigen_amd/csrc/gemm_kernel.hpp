@@ -1,0 +1,430 @@
+// MFMA GEMM kernels for gfx950 (MI355X): C = alpha * op(A) * op(B) + beta * C
+// for float, double, complex<float>, complex<double>, column-major C.
+//
+// This replaces the reference's pack + micro-kernel pipeline
+//   gemm_pack_lhs  (Eigen/src/Core/products/GeneralBlockPanelKernel.h:2090-2369)
+//   gemm_pack_rhs  (GeneralBlockPanelKernel.h:2378-2603)
+//   gebp_kernel    (GeneralBlockPanelKernel.h:1404-2073)
+// driven by general_matrix_matrix_product::run (GeneralMatrixMatrix.h:52-207).
+// On the GPU the "packing" is the global -> LDS tile copy (128-bit loads, no
+// packed buffer in HBM) and the register micro-tile is a grid of MFMA tiles per
+// wavefront.  The alpha scaling and the beta pre-pass of the BLAS wrapper
+// (blas/level3_impl.h:62-66) are fused into the epilogue.
+//
+// Operand layouts.  Each operand is described by which logical dimension is
+// contiguous in memory: "X-contiguous" (the non-reduction index m or n runs
+// fastest: A for op(A)=A, B for op(B)=B^T) or "K-contiguous" (A^T / A^H, and
+// plain B).  The LDS image keeps the same contiguous dimension as global
+// memory, so every global read and LDS write is a 16-byte vector; only the
+// fragment reads differ between the two layouts.
+//
+// MFMA operand roles are swapped with respect to the matrices: the MFMA "A"
+// operand carries B-matrix columns and the MFMA "B" operand carries A-matrix
+// rows, so the accumulator lanes run along m and the C stores of a wavefront
+// are contiguous along C's columns.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace eigamd {
+
+enum Kind : int { F32 = 0, F64 = 1, C32 = 2, C64 = 3 };
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef float f16_t __attribute__((ext_vector_type(16)));
+
+struct GemmParams {
+  const void* A;
+  const void* B;
+  void* C;
+  int64_t lda, ldb, ldc;  // leading dimensions, in elements
+  int M, N, K;            // extents of this launch (relative to A, B, C)
+  int tiles_m, tiles_n;   // grid decomposition
+  double alpha[2];        // (re, im)
+  double beta[2];
+  int conj_a, conj_b;     // complex only: conjugate the operand's elements
+};
+
+constexpr int kThreads = 256;  // 4 wavefronts, 2 x 2 over the block tile
+
+template <int KIND> struct Traits;
+
+template <> struct Traits<F32> {
+  typedef float Elem;
+  typedef float Real;
+  typedef f16_t Acc;
+  static constexpr bool kCplx = false;
+  static constexpr int TM = 32, KS = 2, NACC = 16;  // v_mfma_f32_32x32x2_f32
+  static constexpr int MT = 2, NT = 2;              // MFMA tiles per wave (m, n)
+  static constexpr int BK = 32;
+  static constexpr int PADX = 0, PADK = 1;
+  static constexpr bool kVecWriteK = false;  // odd pitch: element-wise LDS writes
+};
+template <> struct Traits<F64> {
+  typedef double Elem;
+  typedef double Real;
+  typedef d4_t Acc;
+  static constexpr bool kCplx = false;
+  static constexpr int TM = 16, KS = 4, NACC = 4;  // v_mfma_f64_16x16x4_f64
+  static constexpr int MT = 4, NT = 4;
+  static constexpr int BK = 16;
+  static constexpr int PADX = 16, PADK = 2;
+  static constexpr bool kVecWriteK = true;
+};
+template <> struct Traits<C32> {
+  typedef float2 Elem;
+  typedef float Real;
+  typedef f16_t Acc;
+  static constexpr bool kCplx = true;
+  static constexpr int TM = 32, KS = 2, NACC = 16;
+  static constexpr int MT = 2, NT = 2;
+  static constexpr int BK = 16;
+  static constexpr int PADX = 0, PADK = 1;
+  static constexpr bool kVecWriteK = false;
+};
+template <> struct Traits<C64> {
+  typedef double2 Elem;
+  typedef double Real;
+  typedef d4_t Acc;
+  static constexpr bool kCplx = true;
+  static constexpr int TM = 16, KS = 4, NACC = 4;
+  static constexpr int MT = 4, NT = 2;
+  static constexpr int BK = 8;
+  static constexpr int PADX = 0, PADK = 2;
+  static constexpr bool kVecWriteK = true;
+};
+
+template <int KIND> struct Geometry {
+  typedef Traits<KIND> T;
+  static constexpr int BM = 2 * T::MT * T::TM;
+  static constexpr int BN = 2 * T::NT * T::TM;
+  static constexpr int BK = T::BK;
+  static constexpr int ES = sizeof(typename T::Elem);
+  static constexpr int EPC = 16 / ES;  // elements per 16-byte chunk
+  static constexpr int lds_elems(bool kcontig, int bx) {
+    return kcontig ? bx * (BK + T::PADK) : BK * (bx + T::PADX);
+  }
+};
+
+__device__ __forceinline__ void mma(d4_t& c, double a, double b) {
+  c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void mma(f16_t& c, float a, float b) {
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float flip(float v, uint32_t mask) {
+  return __uint_as_float(__float_as_uint(v) ^ mask);
+}
+__device__ __forceinline__ double flip(double v, uint32_t mask) {
+  uint64_t u = (uint64_t)__double_as_longlong(v) ^ ((uint64_t)mask << 32);
+  return __longlong_as_double((long long)u);
+}
+
+// Row (MFMA "A"-operand index, mapped to the n direction) of accumulator
+// register r for this lane.  The column is lane % TM for every shape.
+template <int KIND> __device__ __forceinline__ int acc_row(int r, int kk) {
+  if constexpr (Traits<KIND>::TM == 16) return kk + 4 * r;       // f64 16x16x4
+  else return (r & 3) + 8 * (r >> 2) + 4 * kk;                    // f32 32x32x2
+}
+
+// One operand tile: global -> registers -> LDS.
+//   KC   : operand is K-contiguous in memory (and in LDS)
+//   BX   : tile extent along the non-reduction dimension
+// The tile is cut into 16-byte chunks; chunk c = tid + i * kThreads.
+template <int KIND, bool KC, int BX> struct TileIO {
+  typedef Traits<KIND> T;
+  typedef Geometry<KIND> G;
+  typedef typename T::Elem Elem;
+  static constexpr int BK = T::BK;
+  static constexpr int EPC = G::EPC;
+  static constexpr int PITCH = KC ? (BK + T::PADK) : (BX + T::PADX);
+  static constexpr int CPR = (KC ? BK : BX) / EPC;       // chunks per contiguous row
+  static constexpr int NCHUNK = BX * BK / EPC / kThreads;  // chunks per thread
+  static constexpr int ROWSTEP = kThreads / CPR;           // rows advanced per chunk index
+  static_assert(BX * BK % (EPC * kThreads) == 0, "tile must split evenly over the block");
+  static_assert(kThreads % CPR == 0, "a row must be covered by whole thread groups");
+
+  int row0;   // first row (k for X-contiguous, x for K-contiguous) of this thread
+  int col0;   // first element inside the row
+
+  __device__ __forceinline__ void init(int tid) {
+    row0 = tid / CPR;
+    col0 = (tid % CPR) * EPC;
+  }
+  // Element offset of this thread's first chunk from the tile origin.
+  __device__ __forceinline__ int64_t goffset(int64_t ld) const {
+    return (int64_t)row0 * ld + col0;
+  }
+  // Unguarded: whole chunks, 16-byte aligned.
+  __device__ __forceinline__ void load(uint4 (&r)[NCHUNK], const Elem* p, int64_t ld) const {
+#pragma unroll
+    for (int i = 0; i < NCHUNK; ++i)
+      r[i] = *reinterpret_cast<const uint4*>(p + (int64_t)(i * ROWSTEP) * ld);
+  }
+  // Guarded: element-wise, zero outside [0,xrem) x [0,krem).  Needs only
+  // element alignment.
+  __device__ __forceinline__ void load_guard(uint4 (&r)[NCHUNK], const Elem* p, int64_t ld,
+                                             int xrem, int krem) const {
+#pragma unroll
+    for (int i = 0; i < NCHUNK; ++i) {
+      union { uint4 v; Elem e[EPC]; } u;
+      const int row = row0 + i * ROWSTEP;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const int col = col0 + e;
+        const int x = KC ? row : col;
+        const int k = KC ? col : row;
+        Elem z = {};
+        u.e[e] = (x < xrem && k < krem) ? p[(int64_t)(i * ROWSTEP) * ld + e] : z;
+      }
+      r[i] = u.v;
+    }
+  }
+  __device__ __forceinline__ void store(const uint4 (&r)[NCHUNK], Elem* lds) const {
+#pragma unroll
+    for (int i = 0; i < NCHUNK; ++i) {
+      Elem* dst = lds + (row0 + i * ROWSTEP) * PITCH + col0;
+      if constexpr (!KC || T::kVecWriteK) {
+        *reinterpret_cast<uint4*>(dst) = r[i];
+      } else {
+        union { uint4 v; Elem e[EPC]; } u;
+        u.v = r[i];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) dst[e] = u.e[e];
+      }
+    }
+  }
+  // LDS element index of fragment element (x, k).
+  __device__ static __forceinline__ int frag_index(int x, int k) {
+    return KC ? x * PITCH + k : k * PITCH + x;
+  }
+};
+
+template <int KIND, bool AK, bool BKC, bool GUARD>
+__global__ void __launch_bounds__(kThreads, 2) gemm_kernel(const GemmParams p) {
+  typedef Traits<KIND> T;
+  typedef Geometry<KIND> G;
+  typedef typename T::Elem Elem;
+  typedef typename T::Real Real;
+  typedef typename T::Acc Acc;
+  constexpr int BM = G::BM, BN = G::BN, BK = G::BK;
+  constexpr int TM = T::TM, KS = T::KS, MT = T::MT, NT = T::NT;
+  typedef TileIO<KIND, AK, BM> IOA;
+  typedef TileIO<KIND, BKC, BN> IOB;
+  constexpr int LDS_A = G::lds_elems(AK, BM);
+  constexpr int LDS_B = G::lds_elems(BKC, BN);
+
+  __shared__ __attribute__((aligned(16))) Elem smem[2 * (LDS_A + LDS_B)];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int xi = lane % TM;
+  const int kk = lane / TM;
+  const int wm0 = (wave & 1) * (MT * TM);
+  const int wn0 = (wave >> 1) * (NT * TM);
+
+  // Block -> tile mapping.  Consecutive block ids are dealt round-robin over
+  // the 8 XCDs; give each XCD a contiguous run of the tile sequence, and walk
+  // the sequence in groups of 8 tile rows so that co-resident blocks of one
+  // XCD share A and B panels in that XCD's L2.
+  int tile_m, tile_n;
+  {
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int q = nblk >> 3, rem = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int seq = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+    constexpr int GM = 8;
+    const int per_group = GM * p.tiles_n;
+    const int g = seq / per_group;
+    const int first_m = g * GM;
+    const int gsize = min(p.tiles_m - first_m, GM);
+    const int in_g = seq - g * per_group;
+    tile_m = first_m + in_g % gsize;
+    tile_n = in_g / gsize;
+  }
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  const Elem* __restrict__ A = static_cast<const Elem*>(p.A);
+  const Elem* __restrict__ B = static_cast<const Elem*>(p.B);
+
+  IOA ioa; ioa.init(tid);
+  IOB iob; iob.init(tid);
+  // Tile origins: A tile = rows [m0, m0+BM) x k; B tile = k x cols [n0, n0+BN).
+  const Elem* pa = A + (AK ? (int64_t)m0 * p.lda : (int64_t)m0) + ioa.goffset(p.lda);
+  const Elem* pb = B + (BKC ? (int64_t)n0 * p.ldb : (int64_t)n0) + iob.goffset(p.ldb);
+  const int64_t stepa = AK ? (int64_t)BK : (int64_t)BK * p.lda;
+  const int64_t stepb = BKC ? (int64_t)BK : (int64_t)BK * p.ldb;
+  const int mrem = p.M - m0, nrem = p.N - n0;
+
+  uint4 ra[IOA::NCHUNK], rb[IOB::NCHUNK];
+
+  Acc acc[NT][MT][T::kCplx ? 2 : 1];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int c = 0; c < (T::kCplx ? 2 : 1); ++c)
+#pragma unroll
+        for (int r = 0; r < T::NACC; ++r) acc[j][i][c][r] = 0;
+
+  // Sign masks for the complex product (see the accumulate step below).
+  uint32_t mask_r = 0, mask_i = 0;
+  if constexpr (T::kCplx) {
+    const bool same = (p.conj_a != 0) == (p.conj_b != 0);
+    mask_r = same ? 0x80000000u : 0u;
+    mask_i = same ? 0u : 0x80000000u;
+  }
+
+  const int ntiles = (p.K + BK - 1) / BK;
+  auto gload = [&](int t) {
+    const int krem = p.K - t * BK;
+    if (GUARD || krem < BK) {
+      ioa.load_guard(ra, pa, p.lda, mrem, krem);
+      iob.load_guard(rb, pb, p.ldb, nrem, krem);
+    } else {
+      ioa.load(ra, pa, p.lda);
+      iob.load(rb, pb, p.ldb);
+    }
+    pa += stepa;
+    pb += stepb;
+  };
+
+  if (ntiles > 0) {
+    gload(0);
+    ioa.store(ra, smem);
+    iob.store(rb, smem + LDS_A);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const Elem* sa = smem + (t & 1) * (LDS_A + LDS_B);
+    const Elem* sb = sa + LDS_A;
+    const bool more = t + 1 < ntiles;
+    if (more) gload(t + 1);
+
+#pragma unroll
+    for (int ks = 0; ks < BK / KS; ++ks) {
+      Elem fa[MT], fb[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) fa[i] = sa[IOA::frag_index(wm0 + i * TM + xi, ks * KS + kk)];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) fb[j] = sb[IOB::frag_index(wn0 + j * TM + xi, ks * KS + kk)];
+      if constexpr (!T::kCplx) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int i = 0; i < MT; ++i) mma(acc[j][i][0], fb[j], fa[i]);
+      } else {
+        // With sa, sb = -1 for a conjugated operand and +1 otherwise:
+        //   Re += br*ar - (sa*sb) * bi*ai
+        //   Im  = sa * ( br*ai + (sa*sb) * bi*ar )   (the leading sa is applied in the epilogue)
+        // so one sign flip of bi per accumulator covers all four cases.
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const Real br = fb[j].x, bi = fb[j].y;
+          const Real bi_r = flip(bi, mask_r);
+          const Real bi_i = flip(bi, mask_i);
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            mma(acc[j][i][0], br, fa[i].x);
+            mma(acc[j][i][1], br, fa[i].y);
+            mma(acc[j][i][0], bi_r, fa[i].y);
+            mma(acc[j][i][1], bi_i, fa[i].x);
+          }
+        }
+      }
+    }
+
+    if (more) {
+      Elem* da = smem + ((t + 1) & 1) * (LDS_A + LDS_B);
+      ioa.store(ra, da);
+      iob.store(rb, da + LDS_A);
+    }
+    __syncthreads();
+  }
+
+  // Epilogue: C = alpha * acc + beta * C.  beta == 0 never reads C
+  // (blas/level3_impl.h:64: NaN/Inf in C must not propagate).
+  Elem* __restrict__ C = static_cast<Elem*>(p.C);
+  if constexpr (!T::kCplx) {
+    const Real alpha = (Real)p.alpha[0], beta = (Real)p.beta[0];
+    const bool use_c = p.beta[0] != 0.0;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int m = wm0 + i * TM + xi;
+#pragma unroll
+        for (int r = 0; r < T::NACC; ++r) {
+          const int n = wn0 + j * TM + acc_row<KIND>(r, kk);
+          if (!GUARD || (m < mrem && n < nrem)) {
+            Elem* dst = C + (int64_t)(m0 + m) + (int64_t)(n0 + n) * p.ldc;
+            Real v = alpha * acc[j][i][0][r];
+            if (use_c) v = fma(beta, *dst, v);
+            *dst = v;
+          }
+        }
+      }
+  } else {
+    const Real ar = (Real)p.alpha[0], ai = (Real)p.alpha[1];
+    const Real br = (Real)p.beta[0], bi = (Real)p.beta[1];
+    const bool use_c = p.beta[0] != 0.0 || p.beta[1] != 0.0;
+    const Real sgn = p.conj_a ? (Real)-1 : (Real)1;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int m = wm0 + i * TM + xi;
+#pragma unroll
+        for (int r = 0; r < T::NACC; ++r) {
+          const int n = wn0 + j * TM + acc_row<KIND>(r, kk);
+          if (!GUARD || (m < mrem && n < nrem)) {
+            Elem* dst = C + (int64_t)(m0 + m) + (int64_t)(n0 + n) * p.ldc;
+            const Real pr = acc[j][i][0][r], pi = sgn * acc[j][i][1][r];
+            Elem v;
+            v.x = ar * pr - ai * pi;
+            v.y = ar * pi + ai * pr;
+            if (use_c) {
+              const Elem c = *dst;
+              v.x += br * c.x - bi * c.y;
+              v.y += br * c.y + bi * c.x;
+            }
+            *dst = v;
+          }
+        }
+      }
+  }
+}
+
+// C = beta * C over an m x n window (the k == 0 case of the BLAS wrapper,
+// blas/level3_impl.h:62-69).
+template <int KIND>
+__global__ void scale_kernel(void* Cv, int64_t ldc, int M, int N, double beta_re, double beta_im) {
+  typedef typename Traits<KIND>::Elem Elem;
+  typedef typename Traits<KIND>::Real Real;
+  Elem* C = static_cast<Elem*>(Cv);
+  const int64_t total = (int64_t)M * N;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = idx / M, m = idx - n * M;
+    Elem* dst = C + m + n * ldc;
+    if constexpr (!Traits<KIND>::kCplx) {
+      *dst = beta_re == 0.0 ? (Real)0 : (Real)beta_re * *dst;
+    } else {
+      Elem v = {};
+      if (beta_re != 0.0 || beta_im != 0.0) {
+        const Elem c = *dst;
+        v.x = (Real)beta_re * c.x - (Real)beta_im * c.y;
+        v.y = (Real)beta_re * c.y + (Real)beta_im * c.x;
+      }
+      *dst = v;
+    }
+  }
+}
+
+}  // namespace eigamd

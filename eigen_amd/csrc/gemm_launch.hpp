@@ -1,0 +1,91 @@
+// Host-side launcher for the MFMA GEMM kernels: splits C into an interior
+// region of whole block tiles (vector loads, no bounds checks) and up to two
+// guarded edge strips.  One translation unit per scalar kind instantiates
+// launch_gemm<KIND>.
+#pragma once
+#include "gemm_kernel.hpp"
+
+namespace eigamd {
+
+// op codes shared by every entry point
+enum Op : int { OP_N = 0, OP_T = 1, OP_C = 2, OP_CONJ = 3 /* conj, no transpose */ };
+
+struct GemmCall {
+  int kind;
+  int opa, opb;
+  int64_t m, n, k;
+  double alpha[2], beta[2];
+  const void* A; int64_t lda;
+  const void* B; int64_t ldb;
+  void* C; int64_t ldc;
+};
+
+hipError_t launch_gemm_f32(const GemmCall&, hipStream_t);
+hipError_t launch_gemm_f64(const GemmCall&, hipStream_t);
+hipError_t launch_gemm_c32(const GemmCall&, hipStream_t);
+hipError_t launch_gemm_c64(const GemmCall&, hipStream_t);
+
+template <int KIND, bool AK, bool BKC, bool GUARD>
+static hipError_t launch_region(const GemmCall& c, int64_t r0, int64_t c0, int64_t rows,
+                                int64_t cols, hipStream_t stream) {
+  typedef Geometry<KIND> G;
+  typedef typename Traits<KIND>::Elem Elem;
+  if (rows <= 0 || cols <= 0) return hipSuccess;
+  GemmParams p;
+  const Elem* A = static_cast<const Elem*>(c.A);
+  const Elem* B = static_cast<const Elem*>(c.B);
+  Elem* C = static_cast<Elem*>(c.C);
+  p.A = A + (AK ? r0 * c.lda : r0);
+  p.B = B + (BKC ? c0 * c.ldb : c0);
+  p.C = C + r0 + c0 * c.ldc;
+  p.lda = c.lda; p.ldb = c.ldb; p.ldc = c.ldc;
+  p.M = (int)rows; p.N = (int)cols; p.K = (int)c.k;
+  p.tiles_m = (int)((rows + G::BM - 1) / G::BM);
+  p.tiles_n = (int)((cols + G::BN - 1) / G::BN);
+  p.alpha[0] = c.alpha[0]; p.alpha[1] = c.alpha[1];
+  p.beta[0] = c.beta[0]; p.beta[1] = c.beta[1];
+  p.conj_a = (c.opa == OP_C || c.opa == OP_CONJ);
+  p.conj_b = (c.opb == OP_C || c.opb == OP_CONJ);
+  const int64_t nblk = (int64_t)p.tiles_m * p.tiles_n;
+  if (nblk > 0x7fffffff) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((gemm_kernel<KIND, AK, BKC, GUARD>), dim3((unsigned)nblk), dim3(kThreads), 0,
+                     stream, p);
+  return hipGetLastError();
+}
+
+template <int KIND, bool AK, bool BKC>
+static hipError_t launch_layout(const GemmCall& c, hipStream_t stream) {
+  typedef Geometry<KIND> G;
+  constexpr int ES = G::ES;
+  const bool aligned = ((uintptr_t)c.A % 16 == 0) && ((uintptr_t)c.B % 16 == 0) &&
+                       ((c.lda * ES) % 16 == 0) && ((c.ldb * ES) % 16 == 0);
+  const int64_t mi = aligned ? (c.m / G::BM) * G::BM : 0;
+  const int64_t ni = aligned ? (c.n / G::BN) * G::BN : 0;
+  hipError_t e;
+  if (mi > 0 && ni > 0) {
+    e = launch_region<KIND, AK, BKC, false>(c, 0, 0, mi, ni, stream);
+    if (e != hipSuccess) return e;
+    e = launch_region<KIND, AK, BKC, true>(c, mi, 0, c.m - mi, c.n, stream);  // bottom strip
+    if (e != hipSuccess) return e;
+    return launch_region<KIND, AK, BKC, true>(c, 0, ni, mi, c.n - ni, stream);  // right strip
+  }
+  return launch_region<KIND, AK, BKC, true>(c, 0, 0, c.m, c.n, stream);
+}
+
+template <int KIND>
+static hipError_t launch_gemm(const GemmCall& c, hipStream_t stream) {
+  if (c.m <= 0 || c.n <= 0) return hipSuccess;
+  if (c.k <= 0) {
+    const int64_t total = c.m * c.n;
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL((scale_kernel<KIND>), dim3(blocks), dim3(256), 0, stream, c.C, c.ldc,
+                       (int)c.m, (int)c.n, c.beta[0], c.beta[1]);
+    return hipGetLastError();
+  }
+  const bool ak = (c.opa == OP_T || c.opa == OP_C);    // op(A) = A^T / A^H: k runs fastest
+  const bool bk = (c.opb == OP_N || c.opb == OP_CONJ);  // plain B: k runs fastest
+  if (ak) return bk ? launch_layout<KIND, true, true>(c, stream) : launch_layout<KIND, true, false>(c, stream);
+  return bk ? launch_layout<KIND, false, true>(c, stream) : launch_layout<KIND, false, false>(c, stream);
+}
+
+}  // namespace eigamd

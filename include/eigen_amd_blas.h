@@ -1,0 +1,89 @@
+/* C ABI of libeigen_amd_blas.so: the MI355X (gfx950) implementation of Eigen's
+ * dense matrix-matrix product path.  Plain pointers and sizes only.
+ *
+ * Every entry point names the reference interface (path relative to the Eigen
+ * source tree) that it replaces or extends.
+ */
+#ifndef EIGEN_AMD_BLAS_H
+#define EIGEN_AMD_BLAS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Scalar kinds (argument `dtype`). */
+enum { EIGAMD_F32 = 0, EIGAMD_F64 = 1, EIGAMD_C32 = 2, EIGAMD_C64 = 3 };
+
+/* Operand forms (arguments `opa`, `opb`).  N/T/C are the F77 'N','T','C'
+ * (blas/common.h:47-50).  CONJ (conjugate without transposition) has no F77
+ * spelling; Eigen reaches it from operator* and its BLAS binding materialises a
+ * temporary for it (Eigen/src/Core/products/GeneralMatrixMatrix_BLAS.h:93-105). */
+enum { EIGAMD_OP_N = 0, EIGAMD_OP_T = 1, EIGAMD_OP_C = 2, EIGAMD_OP_CONJ = 3 };
+
+/* Return codes of the eigamd_* entry points. */
+enum {
+  EIGAMD_OK = 0,
+  EIGAMD_ERR_ARG = -1,     /* invalid argument (the F77 entry points call xerbla_ instead) */
+  EIGAMD_ERR_DEVICE = -2,  /* HIP runtime error; eigamd_last_error() has the text */
+  EIGAMD_ERR_NO_GPU = -3   /* no gfx950 device visible: there is no CPU fallback */
+};
+
+/* ---- F77 BLAS ABI, host pointers --------------------------------------------
+ * Replace EIGEN_BLAS_FUNC(gemm) (blas/level3_impl.h:12-76; prototypes
+ * Eigen/src/misc/blas.h:347-351).  Same validation order and info codes
+ * (1,2,3,4,5,8,10,13 -> xerbla_("?GEMM ", &info, 6)), same quick returns, beta == 0
+ * overwrites without reading C, only C(0:m,0:n) is written.  Complex scalars are
+ * passed as pointers to (re,im) pairs.  Return 0. */
+int sgemm_(const char* transa, const char* transb, const int* m, const int* n, const int* k,
+           const float* alpha, const float* a, const int* lda, const float* b, const int* ldb,
+           const float* beta, float* c, const int* ldc);
+int dgemm_(const char* transa, const char* transb, const int* m, const int* n, const int* k,
+           const double* alpha, const double* a, const int* lda, const double* b, const int* ldb,
+           const double* beta, double* c, const int* ldc);
+int cgemm_(const char* transa, const char* transb, const int* m, const int* n, const int* k,
+           const float* alpha, const float* a, const int* lda, const float* b, const int* ldb,
+           const float* beta, float* c, const int* ldc);
+int zgemm_(const char* transa, const char* transb, const int* m, const int* n, const int* k,
+           const double* alpha, const double* a, const int* lda, const double* b, const int* ldb,
+           const double* beta, double* c, const int* ldc);
+
+/* ---- 64-bit host-pointer entry -----------------------------------------------
+ * What general_matrix_matrix_product<...,ColMajor,1>::run computes
+ * (Eigen/src/Core/products/GeneralMatrixMatrix.h:63-69): C = alpha*op(A)*op(B) +
+ * beta*C with 64-bit extents and the CONJ operand form.  alpha/beta point to one
+ * scalar of kind `dtype`.  Used by the header-level binding. */
+int eigamd_gemm_host(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k,
+                     const void* alpha, const void* a, int64_t lda, const void* b, int64_t ldb,
+                     const void* beta, void* c, int64_t ldc);
+
+/* ---- device-pointer entry ----------------------------------------------------
+ * Same operation on matrices already resident in HBM (hipMalloc memory of the
+ * current device).  Asynchronous on `stream` (a hipStream_t, NULL = default
+ * stream).  Element alignment is enough; 16-byte aligned bases and leading
+ * dimensions take the vector-load kernels. */
+int eigamd_gemm_dev(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k,
+                    const void* alpha, const void* d_a, int64_t lda, const void* d_b,
+                    int64_t ldb, const void* beta, void* d_c, int64_t ldc, void* stream);
+
+/* ---- synthetic operands ------------------------------------------------------
+ * U[-1,1) entries from a counter-based generator: element (i,j) depends only on
+ * (seed, i, j), so host and device produce bit-identical matrices without a
+ * transfer.  Mirrors the operand set-up of bench/bench_gemm.cpp:243-246
+ * (setRandom), whose std::rand stream is libc-dependent. */
+int eigamd_fill_uniform_dev(int dtype, void* d_x, int64_t rows, int64_t cols, int64_t ld,
+                            uint64_t seed, void* stream);
+int eigamd_fill_uniform_host(int dtype, void* x, int64_t rows, int64_t cols, int64_t ld,
+                             uint64_t seed);
+
+/* ---- misc --------------------------------------------------------------------- */
+const char* eigamd_last_error(void);  /* text of the last failure on this thread */
+int eigamd_device_ok(void);           /* 1 if a gfx950 device is usable, else 0 */
+/* Block-tile extents (m, n, k) the kernels use for `dtype`. */
+void eigamd_tile_shape(int dtype, int* bm, int* bn, int* bk);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EIGEN_AMD_BLAS_H */
