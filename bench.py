@@ -1,0 +1,295 @@
+#!/usr/bin/env python3
+"""Headline benchmark: dense GEMM throughput of the HIP path on MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+      one step = one C += A*B, double precision, 16384^3, column-major, operands
+      already in HBM (mirrors bench/bench_gemm.cpp:161-165,243-246 of the reference:
+      A, B random in [-1,1), C accumulates).
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+      one step = the same product at 65536^3, A/B/C distributed 2-D block-cyclically
+      over the N GPUs (eigen_amd/summa.py: panel broadcasts over RCCL, one local GEMM
+      per k-panel).  Fixed total work => "scaling": "strong".
+
+Prints ONE JSON line on rank 0.  `value` is whole-job TFLOP/s (2*n^3*steps / wall
+time, max over ranks, barrier + device synchronize on both sides).  `roofline` is
+the dominant kernel (the fp64 MFMA GEMM) priced against the fp64 matrix peak, from
+HIP events recorded around every launch on the launch stream.  `cpu_baseline` is
+Eigen's own multithreaded operator* product (oracle/_ref, built from the
+reference) timed on this host on a bounded sample -- context, not a target.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# Dense MFMA peaks (TFLOP/s).  f32: 64 FLOP/clk/SIMD * 4 SIMD * 256 CU * 2.4 GHz.
+# f64: v_mfma_f64_16x16x4_f64 issues at half that rate (32 FLOP/clk/SIMD).
+PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3, "c64": 78.6, "c32": 157.3}
+KIND = {"f32": 0, "f64": 1, "c32": 2, "c64": 3}
+BLAS_LETTER = {"f32": "s", "f64": "d", "c32": "c", "c64": "z"}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--size", type=int, default=None, help="n of the n^3 product (default 16384 on 1 GPU, 65536 on >1)")
+    ap.add_argument("--dtype", default="f64", choices=list(KIND))
+    ap.add_argument("--kb", type=int, default=2048, help="block size of the block-cyclic layout (= k-panel width)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the sgemm / complex side measurements")
+    ap.add_argument("--cpu-size", type=int, default=8192)
+    return ap.parse_args()
+
+
+class TimedGemm:
+    """Wraps gemm_dev: records a HIP event pair around every launch on the launch stream."""
+
+    def __init__(self):
+        self.events = []
+        self.enabled = False
+
+    def __call__(self, alpha, a, b, beta, c):
+        import torch
+        from eigen_amd.device import gemm_dev
+        if self.enabled:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            gemm_dev("N", "N", alpha, a, b, beta, c)
+            e1.record()
+            self.events.append((e0, e1, 2.0 * c.rows * c.cols * a.cols * (4 if c.kind >= 2 else 1)))
+        else:
+            gemm_dev("N", "N", alpha, a, b, beta, c)
+
+    def summary(self):
+        ms = [e0.elapsed_time(e1) for e0, e1, _ in self.events]
+        flops = [f for _, _, f in self.events]
+        return ms, flops
+
+
+def sampled_ratio(kind, n, c_rows_cols_getter, steps_done, nsamp=24):
+    """Test ratio of sampled C entries after `steps_done` accumulations of A*B onto C0
+    (operands regenerated on the host from the counter-based generator)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import rng_np
+    dt = [np.float32, np.float64, np.complex64, np.complex128][kind]
+    rng = np.random.default_rng(99)
+    rows = np.unique(np.concatenate([[0, n - 1], rng.integers(0, n, nsamp)]))
+    cols = np.unique(np.concatenate([[0, n - 1], rng.integers(0, n, nsamp)]))
+    kk = np.arange(n)
+    a_rows = rng_np.entries(dt, 1, rows[:, None], kk[None, :])
+    b_cols = rng_np.entries(dt, 2, kk[:, None], cols[None, :])
+    c0 = rng_np.entries(dt, 3, rows[:, None], cols[None, :])
+    wide = np.complex128 if kind >= 2 else np.float64
+    prod = a_rows.astype(wide) @ b_cols.astype(wide)
+    want = c0.astype(wide) + steps_done * prod
+    got, mask = c_rows_cols_getter(rows, cols)  # got: values, mask: which (row, col) are available
+    abs1 = (lambda z: np.abs(z.real) + np.abs(z.imag))
+    gauge = steps_done * (abs1(a_rows).astype(np.float64) @ abs1(b_cols).astype(np.float64)) + abs1(c0)
+    eps = 2.0 ** -23 if kind in (0, 2) else 2.0 ** -52
+    r = abs1(got.astype(np.complex128) - want) / (eps * gauge)
+    r = r[mask]
+    return float(r.max()) if r.size else 0.0
+
+
+def cpu_baseline(args):
+    """Eigen's own CPU product on this host: c.noalias() += a*b, best of 2 after a
+    warm-up, through the reference build under oracle/_ref (multithreaded, OpenMP)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        import oracle_lib as ol
+    except Exception as e:  # oracle not built
+        return {"value": None, "unit": "TFLOP/s", "cores": 0, "kind": "reference", "sample": f"unavailable: {e}"}
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    ref = ol.load_ref()
+    n = args.cpu_size
+    if ref is not None:
+        ref.ref_set_threads(threads)
+        secs = ref.ref_bench_gemm(1, n, n, n, 2)
+        return {"value": round(2.0 * n ** 3 / secs / 1e12, 4), "unit": "TFLOP/s", "cores": int(ref.ref_num_threads()),
+                "kind": "reference",
+                "sample": f"Eigen operator* (c.noalias()+=a*b) double {n}^3, best of 2, {ref.variant} "
+                          f"[{ref.ref_simd().decode()}], {2.0 * n ** 3 / (2.0 * 16384 ** 3):.4f} of one step's flops",
+                "seconds": round(secs, 4)}
+    # fall back to the C restatement (single thread) on a smaller sample
+    import numpy as np
+    import eigen_amd
+    n = 1024
+    a = eigen_amd.fill_uniform_host(np.float64, n, n, 1)
+    b = eigen_amd.fill_uniform_host(np.float64, n, n, 2)
+    c = np.ones((n, n), order="F")
+    t0 = time.perf_counter()
+    ol.call_f77(ol.oracle_gemm(1), "N", "N", n, n, n, 1.0, a, n, b, n, 1.0, c, n)
+    secs = time.perf_counter() - t0
+    return {"value": round(2.0 * n ** 3 / secs / 1e12, 5), "unit": "TFLOP/s", "cores": 1, "kind": "port",
+            "sample": f"C oracle dgemm {n}^3, one run", "seconds": round(secs, 4)}
+
+
+def side_measurement(dtype, n, steps):
+    """Device-resident C += A*B for another scalar kind; returns TFLOP/s (best step)."""
+    import torch
+    from eigen_amd.device import DeviceMatrix, gemm_dev
+    kind = KIND[dtype]
+    a = DeviceMatrix(n, n, kind).fill_uniform(1)
+    b = DeviceMatrix(n, n, kind).fill_uniform(2)
+    c = DeviceMatrix(n, n, kind).fill_uniform(3)
+    gemm_dev("N", "N", 1.0, a, b, 1.0, c)
+    best = 1e30
+    for _ in range(steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        gemm_dev("N", "N", 1.0, a, b, 1.0, c)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    flops = (8.0 if kind >= 2 else 2.0) * n ** 3
+    return round(flops / best / 1e9, 2)
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import eigen_amd  # noqa: F401  (raises if the HIP library is missing)
+    from eigen_amd import _lib
+    from eigen_amd.device import DeviceMatrix
+    from eigen_amd.summa import DistMatrix, Grid, pgemm
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if _lib.lib.eigamd_device_ok() != 1:
+        raise SystemExit("bench.py needs an MI355X: " + _lib.lib.eigamd_last_error().decode())
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n = args.size or (16384 if world == 1 else 65536)
+    steps = args.steps if args.steps is not None else (10 if world == 1 else 3)
+    warmup = args.warmup if args.warmup is not None else (2 if world == 1 else 1)
+    kind = KIND[args.dtype]
+    cplx = kind >= 2
+    flops_per_step = (8.0 if cplx else 2.0) * float(n) ** 3
+    timed = TimedGemm()
+
+    if world == 1:
+        A = DeviceMatrix(n, n, kind).fill_uniform(1)
+        B = DeviceMatrix(n, n, kind).fill_uniform(2)
+        C = DeviceMatrix(n, n, kind).fill_uniform(3)
+        step = lambda: timed(1.0, A, B, 1.0, C)
+        layout = "single device, column-major, ld = n"
+    else:
+        grid = Grid()
+        nb = args.kb
+        A = DistMatrix(grid, n, n, nb, nb, kind).fill_uniform(1)
+        B = DistMatrix(grid, n, n, nb, nb, kind).fill_uniform(2)
+        C = DistMatrix(grid, n, n, nb, nb, kind).fill_uniform(3)
+        step = lambda: pgemm(1.0, A, B, 1.0, C, local_gemm=timed)
+        layout = f"2-D block-cyclic {grid.nprow}x{grid.npcol}, block {nb}, SUMMA panel broadcast over RCCL"
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timed.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timed.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # parity of what was just timed: sampled entries of C against the host
+    done = warmup + steps
+    if world == 1:
+        def getter(rows, cols):
+            sub = C.as_strided()[torch.as_tensor(rows, device="cuda")][:, torch.as_tensor(cols, device="cuda")]
+            return sub.cpu().numpy(), np.ones((len(rows), len(cols)), dtype=bool)
+    else:
+        def getter(rows, cols):
+            gr, gc = C.global_rows(), C.global_cols()
+            rpos = {int(g): i for i, g in enumerate(gr)}
+            cpos = {int(g): i for i, g in enumerate(gc)}
+            got = np.zeros((len(rows), len(cols)), dtype=[np.float32, np.float64, np.complex64, np.complex128][kind])
+            mask = np.zeros((len(rows), len(cols)), dtype=bool)
+            loc = C.local.as_strided()
+            for i, r in enumerate(rows):
+                for j, c in enumerate(cols):
+                    if int(r) in rpos and int(c) in cpos:
+                        got[i, j] = loc[rpos[int(r)], cpos[int(c)]].item()
+                        mask[i, j] = True
+            return got, mask
+    ratio = sampled_ratio(kind, n, getter, done)
+    if world > 1:
+        t = torch.tensor([ratio], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ratio = float(t.item())
+
+    ms, fl = timed.summary()
+    kernel_tflops = sum(fl) / (sum(ms) * 1e-3) / 1e12 if ms else 0.0
+    peak = PEAK_TFLOPS[args.dtype]
+    value = flops_per_step * steps / elapsed / 1e12
+
+    if rank == 0:
+        out = {
+            "metric": "GEMM TFLOP/s",
+            "value": round(value, 3),
+            "unit": "TFLOP/s",
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"{BLAS_LETTER[args.dtype]}gemm {n}^3 C += A*B (alpha=1, beta=1, NN, column-major)",
+                       "layout": layout, "n": n, "global_flops_per_step": flops_per_step},
+            "pct_of_peak": round(100.0 * value / (peak * world), 2),
+            "parity_max_test_ratio": round(ratio, 3),
+            "parity_limit": 16.0,
+            "roofline": {"bound": "mfma", "achieved": round(kernel_tflops, 3), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(kernel_tflops / peak, 4), "traffic": None,
+                         "kernel": "eigamd::gemm_kernel<F64, A m-contiguous, B k-contiguous>",
+                         "launches": len(ms), "avg_launch_ms": round(sum(ms) / max(len(ms), 1), 4),
+                         "flops_per_launch": fl[0] if fl else 0},
+        }
+        if world == 1:
+            if not args.no_extra:
+                out["extra"] = {
+                    "sgemm_16384_tflops": side_measurement("f32", 16384, 3),
+                    "zgemm_8192_tflops": side_measurement("c64", 8192, 3),
+                    "cgemm_8192_tflops": side_measurement("c32", 8192, 3),
+                }
+                out["extra"]["sgemm_pct_of_peak"] = round(100 * out["extra"]["sgemm_16384_tflops"] / PEAK_TFLOPS["f32"], 2)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

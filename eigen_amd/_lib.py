@@ -1,0 +1,76 @@
+"""ctypes binding of libeigen_amd_blas.so (declarations: include/eigen_amd_blas.h).
+
+The library is built in-tree by ``make -C eigen_amd/csrc`` (or
+``__graft_entry__.build()``).  There is no fallback: if the shared object is
+missing, importing this module raises, and every compute entry point reports
+an error when no gfx950 device is visible.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libeigen_amd_blas.so")
+
+F32, F64, C32, C64 = 0, 1, 2, 3
+OP_N, OP_T, OP_C, OP_CONJ = 0, 1, 2, 3
+OK, ERR_ARG, ERR_DEVICE, ERR_NO_GPU = 0, -1, -2, -3
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise LibraryMissing(
+            f"{LIB_PATH} not found: build it with `make -C eigen_amd/csrc` "
+            "(hipcc --offload-arch=gfx950); eigen_amd has no CPU implementation")
+    return ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+
+
+lib = _load()
+
+_i32p = ctypes.POINTER(ctypes.c_int)
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+
+for _name in ("sgemm_", "dgemm_", "cgemm_", "zgemm_"):
+    _f = getattr(lib, _name)
+    _f.restype = ctypes.c_int
+    _f.argtypes = [ctypes.c_char_p, ctypes.c_char_p, _i32p, _i32p, _i32p, _vp, _vp, _i32p, _vp, _i32p,
+                   _vp, _vp, _i32p]
+
+lib.eigamd_gemm_host.restype = ctypes.c_int
+lib.eigamd_gemm_host.argtypes = [ctypes.c_int] * 3 + [_i64] * 3 + [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64]
+lib.eigamd_gemm_dev.restype = ctypes.c_int
+lib.eigamd_gemm_dev.argtypes = [ctypes.c_int] * 3 + [_i64] * 3 + [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp]
+lib.eigamd_fill_uniform_dev.restype = ctypes.c_int
+lib.eigamd_fill_uniform_dev.argtypes = [ctypes.c_int, _vp, _i64, _i64, _i64, ctypes.c_uint64, _vp]
+lib.eigamd_fill_uniform_cyclic_dev.restype = ctypes.c_int
+lib.eigamd_fill_uniform_cyclic_dev.argtypes = [ctypes.c_int, _vp, _i64, _i64, _i64, ctypes.c_uint64, _i64, ctypes.c_int,
+                                               ctypes.c_int, _i64, ctypes.c_int, ctypes.c_int, _vp]
+lib.eigamd_fill_uniform_host.restype = ctypes.c_int
+lib.eigamd_fill_uniform_host.argtypes = [ctypes.c_int, _vp, _i64, _i64, _i64, ctypes.c_uint64]
+lib.eigamd_last_error.restype = ctypes.c_char_p
+lib.eigamd_last_error.argtypes = []
+lib.eigamd_device_ok.restype = ctypes.c_int
+lib.eigamd_device_ok.argtypes = []
+lib.eigamd_tile_shape.restype = None
+lib.eigamd_tile_shape.argtypes = [ctypes.c_int, _i32p, _i32p, _i32p]
+
+
+class EigenAmdError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        super().__init__(f"{where}: error {code}: {lib.eigamd_last_error().decode(errors='replace')}")
+
+
+def check(code, where):
+    if code != OK:
+        raise EigenAmdError(code, where)
+
+
+def tile_shape(dtype):
+    bm, bn, bk = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    lib.eigamd_tile_shape(dtype, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(bk))
+    return bm.value, bn.value, bk.value

@@ -279,7 +279,22 @@ int eigamd_fill_uniform_dev(int dtype, void* d_x, int64_t rows, int64_t cols, in
   if (rows == 0 || cols == 0) return EIGAMD_OK;
   int rc = ensure_device();
   if (rc != EIGAMD_OK) return rc;
-  HIP_TRY(fill_uniform_device(dtype, d_x, rows, cols, ld, seed, static_cast<hipStream_t>(stream)));
+  const CyclicMap ident = {1, 1, 0};
+  HIP_TRY(fill_uniform_device(dtype, d_x, rows, cols, ld, seed, ident, ident, static_cast<hipStream_t>(stream)));
+  return EIGAMD_OK;
+}
+
+int eigamd_fill_uniform_cyclic_dev(int dtype, void* d_x, int64_t rows, int64_t cols, int64_t ld,
+                                   uint64_t seed, int64_t nb_r, int nprow, int myrow, int64_t nb_c,
+                                   int npcol, int mycol, void* stream) {
+  if (dtype < 0 || dtype > 3 || rows < 0 || cols < 0 || ld < std::max<int64_t>(rows, 1) || nb_r < 1 ||
+      nb_c < 1 || nprow < 1 || npcol < 1 || myrow < 0 || myrow >= nprow || mycol < 0 || mycol >= npcol)
+    return fail(EIGAMD_ERR_ARG, "invalid fill arguments");
+  if (rows == 0 || cols == 0) return EIGAMD_OK;
+  int rc = ensure_device();
+  if (rc != EIGAMD_OK) return rc;
+  const CyclicMap rmap = {nb_r, nprow, myrow}, cmap = {nb_c, npcol, mycol};
+  HIP_TRY(fill_uniform_device(dtype, d_x, rows, cols, ld, seed, rmap, cmap, static_cast<hipStream_t>(stream)));
   return EIGAMD_OK;
 }
 

@@ -35,21 +35,33 @@ template <typename F> __host__ __device__ inline void put_uniform(int dtype, voi
   }
 }
 
-__global__ void fill_uniform_kernel(int dtype, void* x, int64_t rows, int64_t cols, int64_t ld, uint64_t seed) {
+// Block-cyclic index map: local index l of process p (of np, block nb) is global
+// index (l / nb) * nb * np + p * nb + l % nb.  np == 1 is the identity.
+struct CyclicMap {
+  int64_t nb;
+  int np, p;
+  __host__ __device__ int64_t global(int64_t l) const {
+    return np == 1 ? l : (l / nb) * nb * np + (int64_t)p * nb + l % nb;
+  }
+};
+
+__global__ void fill_uniform_kernel(int dtype, void* x, int64_t rows, int64_t cols, int64_t ld, uint64_t seed,
+                                    CyclicMap rmap, CyclicMap cmap) {
   const int64_t total = rows * cols;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t j = idx / rows, i = idx - j * rows;
-    put_uniform<void>(dtype, x, i + j * ld, elem_hash(seed, i, j));
+    put_uniform<void>(dtype, x, i + j * ld, elem_hash(seed, rmap.global(i), cmap.global(j)));
   }
 }
 
 inline hipError_t fill_uniform_device(int dtype, void* x, int64_t rows, int64_t cols, int64_t ld,
-                                      uint64_t seed, hipStream_t stream) {
+                                      uint64_t seed, CyclicMap rmap, CyclicMap cmap, hipStream_t stream) {
   const int64_t total = rows * cols;
   const int64_t want = (total + 255) / 256;
   const unsigned blocks = (unsigned)(want > 16384 ? 16384 : want);
-  hipLaunchKernelGGL(fill_uniform_kernel, dim3(blocks), dim3(256), 0, stream, dtype, x, rows, cols, ld, seed);
+  hipLaunchKernelGGL(fill_uniform_kernel, dim3(blocks), dim3(256), 0, stream, dtype, x, rows, cols, ld, seed,
+                     rmap, cmap);
   return hipGetLastError();
 }
 

@@ -1,0 +1,88 @@
+"""Device-resident matrices and the device-pointer GEMM entry
+(``eigamd_gemm_dev``).  torch is used for HBM allocation and streams only."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib
+
+_TORCH_OF_KIND = {_lib.F32: torch.float32, _lib.F64: torch.float64, _lib.C32: torch.complex64,
+                  _lib.C64: torch.complex128}
+_NP_OF_KIND = {_lib.F32: np.float32, _lib.F64: np.float64, _lib.C32: np.complex64, _lib.C64: np.complex128}
+_KIND_OF_TORCH = {v: k for k, v in _TORCH_OF_KIND.items()}
+_OPCODE = {"N": _lib.OP_N, "T": _lib.OP_T, "C": _lib.OP_C, "J": _lib.OP_CONJ}
+
+
+def _stream_ptr(stream=None):
+    s = torch.cuda.current_stream() if stream is None else stream
+    return ctypes.c_void_p(s.cuda_stream)
+
+
+class DeviceMatrix:
+    """Column-major rows x cols matrix in HBM with leading dimension ``ld``
+    (storage: a 1-D torch tensor of ld*cols elements)."""
+
+    def __init__(self, rows, cols, kind, ld=None, device="cuda", storage=None, offset=0):
+        self.rows, self.cols, self.kind = int(rows), int(cols), int(kind)
+        self.ld = int(max(rows, 1) if ld is None else ld)
+        if self.ld < max(self.rows, 1):
+            raise ValueError("ld < rows")
+        self.offset = int(offset)
+        if storage is None:
+            storage = torch.empty(self.ld * max(self.cols, 1), dtype=_TORCH_OF_KIND[self.kind], device=device)
+        self.storage = storage
+
+    @property
+    def elem_size(self):
+        return self.storage.element_size()
+
+    @property
+    def ptr(self):
+        return self.storage.data_ptr() + self.offset * self.elem_size
+
+    def block(self, r0, c0, rows, cols):
+        """View of the sub-matrix [r0, r0+rows) x [c0, c0+cols) (same storage)."""
+        if r0 < 0 or c0 < 0 or r0 + rows > self.rows or c0 + cols > self.cols:
+            raise IndexError("block out of range")
+        return DeviceMatrix(rows, cols, self.kind, ld=self.ld, storage=self.storage,
+                            offset=self.offset + r0 + c0 * self.ld)
+
+    def fill_uniform(self, seed, stream=None):
+        rc = lib.eigamd_fill_uniform_dev(self.kind, ctypes.c_void_p(self.ptr), self.rows, self.cols, self.ld,
+                                         seed, _stream_ptr(stream))
+        _lib.check(rc, "eigamd_fill_uniform_dev")
+        return self
+
+    def as_strided(self):
+        """torch view of shape (rows, cols) with column-major strides."""
+        return torch.as_strided(self.storage, (self.rows, self.cols), (1, self.ld), self.offset)
+
+    def to_numpy(self):
+        return np.asfortranarray(self.as_strided().cpu().numpy())
+
+    @classmethod
+    def from_numpy(cls, a, ld=None, device="cuda"):
+        a = np.asarray(a)
+        kind = {np.dtype(v): k for k, v in _NP_OF_KIND.items()}[a.dtype]
+        m = cls(a.shape[0], a.shape[1], kind, ld=ld, device=device)
+        m.as_strided().copy_(torch.from_numpy(np.ascontiguousarray(a)))
+        return m
+
+
+def gemm_dev(opa, opb, alpha, a, b, beta, c, stream=None):
+    """c <- alpha * op(a) * op(b) + beta * c on DeviceMatrix operands, asynchronously on
+    ``stream`` (default: torch's current stream)."""
+    if not (a.kind == b.kind == c.kind):
+        raise ValueError("operands must share one scalar kind")
+    oa, ob = _OPCODE[opa], _OPCODE[opb]
+    m, n = c.rows, c.cols
+    k = a.cols if oa in (_lib.OP_N, _lib.OP_CONJ) else a.rows
+    dt = _NP_OF_KIND[c.kind]
+    al, be = np.array([alpha], dtype=dt), np.array([beta], dtype=dt)
+    rc = lib.eigamd_gemm_dev(c.kind, oa, ob, m, n, k, ctypes.c_void_p(al.ctypes.data), ctypes.c_void_p(a.ptr), a.ld,
+                             ctypes.c_void_p(b.ptr), b.ld, ctypes.c_void_p(be.ctypes.data), ctypes.c_void_p(c.ptr),
+                             c.ld, _stream_ptr(stream))
+    _lib.check(rc, "eigamd_gemm_dev")
+    return c

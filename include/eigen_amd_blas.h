@@ -76,6 +76,14 @@ int eigamd_fill_uniform_dev(int dtype, void* d_x, int64_t rows, int64_t cols, in
                             uint64_t seed, void* stream);
 int eigamd_fill_uniform_host(int dtype, void* x, int64_t rows, int64_t cols, int64_t ld,
                              uint64_t seed);
+/* The local part of a matrix distributed 2-D block-cyclically (block nb_r x nb_c
+ * over an nprow x npcol process grid, this process at (myrow, mycol)): local
+ * element (i, j) gets the value of its GLOBAL position, so the distributed matrix
+ * equals the one eigamd_fill_uniform_dev writes on one device.  No counterpart in
+ * the reference (it has no distributed layer); used by the multi-GPU GEMM driver. */
+int eigamd_fill_uniform_cyclic_dev(int dtype, void* d_x, int64_t rows, int64_t cols, int64_t ld,
+                                   uint64_t seed, int64_t nb_r, int nprow, int myrow, int64_t nb_c,
+                                   int npcol, int mycol, void* stream);
 
 /* ---- misc --------------------------------------------------------------------- */
 const char* eigamd_last_error(void);  /* text of the last failure on this thread */

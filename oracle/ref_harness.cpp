@@ -1,0 +1,185 @@
+// Thin C entry points over the *reference itself* (Eigen headers under
+// /root/reference, compiled in place by oracle/Makefile into oracle/_ref/).
+// Used to pin the C oracle, to generate tests/golden/, and as the "reference"
+// CPU baseline of bench.py.  TEST INFRASTRUCTURE ONLY; no Eigen source is copied:
+// this file only *uses* the public API (operator*, noalias, PartialPivLU).
+#include <Eigen/Core>
+#include <Eigen/LU>
+
+#include <chrono>
+#include <complex>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+using namespace Eigen;
+
+namespace {
+
+template <typename S> struct Views {
+  typedef Matrix<S, Dynamic, Dynamic, ColMajor> Mat;
+  typedef Map<const Mat, 0, OuterStride<> > CMap;
+  typedef Map<Mat, 0, OuterStride<> > MMap;
+};
+
+// C = beta*C + alpha * op(A) * op(B) through Eigen's expression templates, the way a
+// user of the library writes it (dispatch: Eigen/src/Core/products/GeneralMatrixMatrix.h:411-513).
+template <typename S>
+void opstar(int opa, int opb, int64_t m, int64_t n, int64_t k, const void* palpha, const void* pa, int64_t lda,
+            const void* pb, int64_t ldb, const void* pbeta, void* pc, int64_t ldc) {
+  typedef typename Views<S>::CMap CMap;
+  typedef typename Views<S>::MMap MMap;
+  const S alpha = *static_cast<const S*>(palpha), beta = *static_cast<const S*>(pbeta);
+  const bool an = (opa == 0 || opa == 3), bn = (opb == 0 || opb == 3);
+  CMap A(static_cast<const S*>(pa), an ? m : k, an ? k : m, OuterStride<>(lda));
+  CMap B(static_cast<const S*>(pb), bn ? k : n, bn ? n : k, OuterStride<>(ldb));
+  MMap C(static_cast<S*>(pc), m, n, OuterStride<>(ldc));
+  if (beta == S(0)) C.setZero();
+  else if (beta != S(1)) C *= beta;
+  if (k == 0) return;
+#define OPSTAR_CASE(code, EA, EB) \
+  case code: C.noalias() += alpha * ((EA) * (EB)); break;
+  switch (opa * 4 + opb) {
+    OPSTAR_CASE(0, A, B)
+    OPSTAR_CASE(1, A, B.transpose())
+    OPSTAR_CASE(2, A, B.adjoint())
+    OPSTAR_CASE(3, A, B.conjugate())
+    OPSTAR_CASE(4, A.transpose(), B)
+    OPSTAR_CASE(5, A.transpose(), B.transpose())
+    OPSTAR_CASE(6, A.transpose(), B.adjoint())
+    OPSTAR_CASE(7, A.transpose(), B.conjugate())
+    OPSTAR_CASE(8, A.adjoint(), B)
+    OPSTAR_CASE(9, A.adjoint(), B.transpose())
+    OPSTAR_CASE(10, A.adjoint(), B.adjoint())
+    OPSTAR_CASE(11, A.adjoint(), B.conjugate())
+    OPSTAR_CASE(12, A.conjugate(), B)
+    OPSTAR_CASE(13, A.conjugate(), B.transpose())
+    OPSTAR_CASE(14, A.conjugate(), B.adjoint())
+    OPSTAR_CASE(15, A.conjugate(), B.conjugate())
+  }
+#undef OPSTAR_CASE
+}
+
+// The timed operation of bench/bench_gemm.cpp:161-165: c.noalias() += a * b in a
+// function the optimiser cannot fold into the caller.
+template <typename M> __attribute__((noinline)) void gemm_step(const M& a, const M& b, M& c) {
+  c.noalias() += a * b;
+}
+
+template <typename S> double bench(int64_t m, int64_t n, int64_t k, int tries) {
+  typedef Matrix<S, Dynamic, Dynamic> M;
+  M a(m, k), b(k, n), c(m, n);
+  a.setRandom();
+  b.setRandom();
+  c.setOnes();  // bench_gemm.cpp:243-246
+  gemm_step(a, b, c);  // warm-up (page faults, thread pool)
+  double best = 1e300;
+  for (int t = 0; t < tries; ++t) {
+    auto t0 = std::chrono::steady_clock::now();
+    gemm_step(a, b, c);
+    auto t1 = std::chrono::steady_clock::now();
+    best = std::min(best, std::chrono::duration<double>(t1 - t0).count());
+  }
+  return best;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ref_opstar(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k, const void* alpha, const void* a,
+               int64_t lda, const void* b, int64_t ldb, const void* beta, void* c, int64_t ldc) {
+  switch (dtype) {
+    case 0: opstar<float>(opa, opb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc); return 0;
+    case 1: opstar<double>(opa, opb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc); return 0;
+    case 2: opstar<std::complex<float> >(opa, opb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc); return 0;
+    case 3: opstar<std::complex<double> >(opa, opb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc); return 0;
+  }
+  return -1;
+}
+
+// Best-of-`tries` wall seconds of one c.noalias() += a*b (multithreaded when built
+// with OpenMP: Eigen/src/Core/products/Parallelizer.h:101-176).
+double ref_bench_gemm(int dtype, int64_t m, int64_t n, int64_t k, int tries) {
+  switch (dtype) {
+    case 0: return bench<float>(m, n, k, tries);
+    case 1: return bench<double>(m, n, k, tries);
+    case 2: return bench<std::complex<float> >(m, n, k, tries);
+    case 3: return bench<std::complex<double> >(m, n, k, tries);
+  }
+  return -1;
+}
+
+// PartialPivLU on a column-major double matrix, in place
+// (Eigen/src/LU/PartialPivLU.h:503-546).  piv[i] = row swapped with row i (0-based,
+// the transpositions Eigen records).  Returns 0.
+int ref_partial_piv_lu(int64_t n, double* a, int64_t lda, int* piv) {
+  typedef Matrix<double, Dynamic, Dynamic, ColMajor> Mat;
+  Map<Mat, 0, OuterStride<> > A(a, n, n, OuterStride<>(lda));
+  PartialPivLU<Mat> lu(A);
+  A = lu.matrixLU();
+  const auto& tr = lu.permutationP().indices();  // permutation, not transpositions
+  // Recover the transposition sequence from the permutation P (P*A = L*U).
+  std::vector<int> perm(n), pos(n);
+  for (int64_t i = 0; i < n; ++i) { perm[i] = (int)i; pos[i] = (int)i; }
+  // P applied to A moves row p(i) ... : indices()[i] = destination of row i.
+  std::vector<int> src(n);
+  for (int64_t i = 0; i < n; ++i) src[tr[i]] = (int)i;  // row i of P*A is row src[i] of A
+  for (int64_t i = 0; i < n; ++i) {
+    const int want = src[i];       // original row that must land at i
+    const int at = pos[want];      // where it currently sits
+    piv[i] = at;
+    const int other = perm[i];
+    perm[at] = other; pos[other] = at;
+    perm[i] = want; pos[want] = (int)i;
+  }
+  return 0;
+}
+
+double ref_bench_lu(int64_t n, int tries) {
+  typedef Matrix<double, Dynamic, Dynamic> M;
+  M a = M::Random(n, n);
+  double best = 1e300;
+  for (int t = 0; t < tries; ++t) {
+    auto t0 = std::chrono::steady_clock::now();
+    PartialPivLU<M> lu(a);
+    auto t1 = std::chrono::steady_clock::now();
+    best = std::min(best, std::chrono::duration<double>(t1 - t0).count());
+    if (lu.matrixLU()(0, 0) == 12345.678) return -1;
+  }
+  return best;
+}
+
+// Cache sizes used by the blocking heuristic (GeneralBlockPanelKernel.h:2640-2643).
+void ref_set_cache_sizes(long l1, long l2, long l3) { Eigen::setCpuCacheSizes(l1, l2, l3); }
+
+// computeProductBlockingSizes for one thread (GeneralBlockPanelKernel.h:340-352).
+void ref_blocking_sizes(int dtype, long* k, long* m, long* n) {
+  Index kk = *k, mm = *m, nn = *n;
+  switch (dtype) {
+    case 0: internal::computeProductBlockingSizes<float, float>(kk, mm, nn, Index(1)); break;
+    case 1: internal::computeProductBlockingSizes<double, double>(kk, mm, nn, Index(1)); break;
+    case 2: internal::computeProductBlockingSizes<std::complex<float>, std::complex<float> >(kk, mm, nn, Index(1)); break;
+    default: internal::computeProductBlockingSizes<std::complex<double>, std::complex<double> >(kk, mm, nn, Index(1)); break;
+  }
+  *k = kk; *m = mm; *n = nn;
+}
+
+// Register-tile extents of gebp_traits (GeneralBlockPanelKernel.h:442-455).
+void ref_register_tile(int dtype, int* mr, int* nr) {
+  switch (dtype) {
+    case 0: *mr = internal::gebp_traits<float, float>::mr; *nr = internal::gebp_traits<float, float>::nr; break;
+    case 1: *mr = internal::gebp_traits<double, double>::mr; *nr = internal::gebp_traits<double, double>::nr; break;
+    case 2: *mr = internal::gebp_traits<std::complex<float>, std::complex<float> >::mr;
+            *nr = internal::gebp_traits<std::complex<float>, std::complex<float> >::nr; break;
+    default: *mr = internal::gebp_traits<std::complex<double>, std::complex<double> >::mr;
+             *nr = internal::gebp_traits<std::complex<double>, std::complex<double> >::nr; break;
+  }
+}
+
+void ref_set_threads(int n) { Eigen::setNbThreads(n); }
+int ref_num_threads(void) { return Eigen::nbThreads(); }
+const char* ref_simd(void) { return Eigen::SimdInstructionSetsInUse(); }
+int ref_version(void) { return EIGEN_WORLD_VERSION * 10000 + EIGEN_MAJOR_VERSION * 100 + EIGEN_MINOR_VERSION; }
+
+}  // extern "C"
