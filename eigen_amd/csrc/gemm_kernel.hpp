@@ -43,6 +43,8 @@ struct GemmParams {
   double alpha[2];        // (re, im)
   double beta[2];
   int conj_a, conj_b;     // complex only: conjugate the operand's elements
+  int group_m;            // tile rows walked together by consecutive blocks (L2 reuse)
+  int xcd_remap;          // 1: give each XCD a contiguous run of the tile sequence
 };
 
 constexpr int kThreads = 256;  // 4 wavefronts, 2 x 2 over the block tile
@@ -235,8 +237,8 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(const GemmParams p) {
     const int bid = blockIdx.x;
     const int q = nblk >> 3, rem = nblk & 7;
     const int xcd = bid & 7, idx = bid >> 3;
-    const int seq = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
-    constexpr int GM = 8;
+    const int seq = p.xcd_remap ? (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx : bid;
+    const int GM = p.group_m;
     const int per_group = GM * p.tiles_n;
     const int g = seq / per_group;
     const int first_m = g * GM;

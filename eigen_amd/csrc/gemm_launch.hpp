@@ -3,6 +3,9 @@
 // guarded edge strips.  One translation unit per scalar kind instantiates
 // launch_gemm<KIND>.
 #pragma once
+#include <algorithm>
+#include <cstdlib>
+
 #include "gemm_kernel.hpp"
 
 namespace eigamd {
@@ -19,6 +22,24 @@ struct GemmCall {
   const void* B; int64_t ldb;
   void* C; int64_t ldc;
 };
+
+// Block-to-tile mapping knobs; the defaults are what the shipped library uses, the
+// environment overrides exist for profiling experiments only.
+struct Tuning {
+  int group_m = 8;
+  int xcd_remap = 1;
+  int extra_lds = 0;  // bytes of unused dynamic LDS per block (lowers blocks per CU)
+};
+inline const Tuning& tuning() {
+  static const Tuning t = [] {
+    Tuning v;
+    if (const char* e = std::getenv("EIGAMD_GROUP_M")) v.group_m = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("EIGAMD_XCD_REMAP")) v.xcd_remap = std::atoi(e) != 0;
+    if (const char* e = std::getenv("EIGAMD_EXTRA_LDS")) v.extra_lds = std::max(0, std::atoi(e));
+    return v;
+  }();
+  return t;
+}
 
 hipError_t launch_gemm_f32(const GemmCall&, hipStream_t);
 hipError_t launch_gemm_f64(const GemmCall&, hipStream_t);
@@ -46,10 +67,12 @@ static hipError_t launch_region(const GemmCall& c, int64_t r0, int64_t c0, int64
   p.beta[0] = c.beta[0]; p.beta[1] = c.beta[1];
   p.conj_a = (c.opa == OP_C || c.opa == OP_CONJ);
   p.conj_b = (c.opb == OP_C || c.opb == OP_CONJ);
+  p.group_m = tuning().group_m;
+  p.xcd_remap = tuning().xcd_remap;
   const int64_t nblk = (int64_t)p.tiles_m * p.tiles_n;
   if (nblk > 0x7fffffff) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((gemm_kernel<KIND, AK, BKC, GUARD>), dim3((unsigned)nblk), dim3(kThreads), 0,
-                     stream, p);
+  hipLaunchKernelGGL((gemm_kernel<KIND, AK, BKC, GUARD>), dim3((unsigned)nblk), dim3(kThreads),
+                     tuning().extra_lds, stream, p);
   return hipGetLastError();
 }
 
