@@ -51,6 +51,15 @@ lib.eigamd_fill_uniform_cyclic_dev.argtypes = [ctypes.c_int, _vp, _i64, _i64, _i
                                                ctypes.c_int, _i64, ctypes.c_int, ctypes.c_int, _vp]
 lib.eigamd_fill_uniform_host.restype = ctypes.c_int
 lib.eigamd_fill_uniform_host.argtypes = [ctypes.c_int, _vp, _i64, _i64, _i64, ctypes.c_uint64]
+_i32ptr = ctypes.POINTER(ctypes.c_int)
+lib.eigamd_blocked_lu_host.restype = ctypes.c_int
+lib.eigamd_blocked_lu_host.argtypes = [ctypes.c_int, _i64, _i64, _vp, _i64, _vp, _i32ptr, _i32ptr]
+lib.eigamd_getrf_dev.restype = ctypes.c_int
+lib.eigamd_getrf_dev.argtypes = [ctypes.c_int, _i64, _i64, _vp, _i64, _vp, _i32ptr, _i32ptr, _vp]
+for _name in ("dgetrf_", "sgetrf_"):
+    _f = getattr(lib, _name)
+    _f.restype = ctypes.c_int
+    _f.argtypes = [_i32p, _i32p, _vp, _i32p, _vp, _i32p]
 lib.eigamd_last_error.restype = ctypes.c_char_p
 lib.eigamd_last_error.argtypes = []
 lib.eigamd_device_ok.restype = ctypes.c_int

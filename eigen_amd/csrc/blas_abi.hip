@@ -14,6 +14,7 @@
 
 #include "../../include/eigen_amd_blas.h"
 #include "gemm_launch.hpp"
+#include "lu.hpp"
 #include "rng.hpp"
 
 using namespace eigamd;
@@ -304,6 +305,86 @@ int eigamd_fill_uniform_host(int dtype, void* x, int64_t rows, int64_t cols, int
     return fail(EIGAMD_ERR_ARG, "invalid fill arguments");
   fill_uniform_host(dtype, x, rows, cols, ld, seed);
   return EIGAMD_OK;
+}
+
+int eigamd_getrf_dev(int dtype, int64_t m, int64_t n, void* d_a, int64_t lda, int* d_transp,
+                     int* first_zero_pivot, int* nb_transpositions, void* stream) {
+  if (dtype != F32 && dtype != F64) return fail(EIGAMD_ERR_ARG, "LU supports the real kinds (f32, f64)");
+  if (m < 0 || n < 0 || lda < std::max<int64_t>(1, m) || m > 0x7fffffff || n > 0x7fffffff)
+    return fail(EIGAMD_ERR_ARG, "invalid LU arguments");
+  int fz = -1, nb = 0;
+  if (m > 0 && n > 0) {
+    int rc = ensure_device();
+    if (rc != EIGAMD_OK) return rc;
+    HIP_TRY(getrf_device(dtype, m, n, d_a, lda, d_transp, &fz, &nb, static_cast<hipStream_t>(stream)));
+  }
+  if (first_zero_pivot) *first_zero_pivot = fz;
+  if (nb_transpositions) *nb_transpositions = nb;
+  return EIGAMD_OK;
+}
+
+// Host-pointer LU: stage in, factorise on the device, copy factors and
+// transpositions back.  Returns the index of the first zero pivot or -1 through
+// *first_zero_pivot, like partial_lu_impl::blocked_lu (PartialPivLU.h:429).
+static int lu_host_impl(int dtype, int64_t m, int64_t n, void* a, int64_t lda, int* transp, int* first_zero_pivot,
+                        int* nb_transpositions) {
+  *first_zero_pivot = -1;
+  *nb_transpositions = 0;
+  if (m == 0 || n == 0) return EIGAMD_OK;
+  int rc = ensure_device();
+  if (rc != EIGAMD_OK) return rc;
+  const int es = kElemSize[dtype];
+  const int64_t dld = round_up(m, 16);
+  const int64_t size = std::min(m, n);
+  Staging& st = staging();
+  std::lock_guard<std::mutex> lock(st.mu);
+  if (!st.stream) HIP_TRY(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
+  if ((rc = st.reserve(2, (size_t)dld * n * es)) != EIGAMD_OK) return rc;
+  if ((rc = st.reserve(0, (size_t)size * sizeof(int) + 64)) != EIGAMD_OK) return rc;
+  HIP_TRY(hipMemcpy2DAsync(st.buf[2], dld * es, a, lda * es, m * es, n, hipMemcpyHostToDevice, st.stream));
+  HIP_TRY(getrf_device(dtype, m, n, st.buf[2], dld, static_cast<int*>(st.buf[0]), first_zero_pivot,
+                       nb_transpositions, st.stream));
+  HIP_TRY(hipMemcpy2DAsync(a, lda * es, st.buf[2], dld * es, m * es, n, hipMemcpyDeviceToHost, st.stream));
+  HIP_TRY(hipMemcpyAsync(transp, st.buf[0], (size_t)size * sizeof(int), hipMemcpyDeviceToHost, st.stream));
+  HIP_TRY(hipStreamSynchronize(st.stream));
+  return EIGAMD_OK;
+}
+
+int eigamd_blocked_lu_host(int dtype, int64_t rows, int64_t cols, void* lu, int64_t lu_stride, int* row_transpositions,
+                           int* nb_transpositions, int* first_zero_pivot) {
+  if (dtype != F32 && dtype != F64) return fail(EIGAMD_ERR_ARG, "LU supports the real kinds (f32, f64)");
+  if (rows < 0 || cols < 0 || lu_stride < std::max<int64_t>(1, rows) || rows > 0x7fffffff || cols > 0x7fffffff)
+    return fail(EIGAMD_ERR_ARG, "invalid LU arguments");
+  return lu_host_impl(dtype, rows, cols, lu, lu_stride, row_transpositions, first_zero_pivot, nb_transpositions);
+}
+
+static int f77_getrf(int dtype, const char* name, const int* m, const int* n, void* a, const int* lda, int* ipiv,
+                     int* info) {
+  *info = 0;                                   // lapack/lu.cpp:16-24
+  if (*m < 0) *info = -1;
+  else if (*n < 0) *info = -2;
+  else if (*lda < std::max(1, *m)) *info = -4;
+  if (*info != 0) {
+    int e = -*info;
+    return xerbla_(name, &e, 6);
+  }
+  if (*m == 0 || *n == 0) return 0;
+  int fz = -1, nb = 0;
+  int rc = lu_host_impl(dtype, *m, *n, a, *lda, ipiv, &fz, &nb);
+  if (rc != EIGAMD_OK) {
+    std::fprintf(stderr, "eigen_amd %s: %s\n", name, g_err.c_str());
+    std::abort();
+  }
+  for (int i = 0; i < std::min(*m, *n); ++i) ipiv[i]++;   // 1-based (lu.cpp:34-35)
+  if (fz >= 0) *info = fz + 1;                            // (lu.cpp:37-38)
+  return 0;
+}
+
+int dgetrf_(const int* m, const int* n, double* a, const int* lda, int* ipiv, int* info) {
+  return f77_getrf(F64, "DGETRF", m, n, a, lda, ipiv, info);
+}
+int sgetrf_(const int* m, const int* n, float* a, const int* lda, int* ipiv, int* info) {
+  return f77_getrf(F32, "SGETRF", m, n, a, lda, ipiv, info);
 }
 
 const char* eigamd_last_error(void) { return g_err.c_str(); }

@@ -1,0 +1,367 @@
+// Device-resident blocked LU with partial pivoting, right-looking, whose trailing
+// update A22 -= A21 * A12 runs on the MFMA GEMM kernels.
+//
+// Mirrors partial_lu_impl::blocked_lu / unblocked_lu of the reference
+// (Eigen/src/LU/PartialPivLU.h:357-498): same block-size rule (:443-448), the same
+// two-level structure (a panel of blockSize columns is itself factorised with
+// blocks of 16 and an unblocked base case, :472-473), the same pivot choice (first
+// row of largest |a|, :375-377), zero-pivot bookkeeping (:391-396) and the same
+// order of row transpositions on the left (A_0) and right (A_2) parts (:479-489).
+// Everything stays in HBM: pivot search, swaps, scaling and rank-1 updates of the
+// base case are small multi-block kernels chained on one stream (a kernel boundary
+// is the grid-wide synchronisation), the pivot indices never visit the host.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <mutex>
+
+#include "gemm_launch.hpp"
+#include "lu.hpp"
+
+namespace eigamd {
+
+namespace {
+
+constexpr int kRowsPerBlock = 256;  // rows of the panel one workgroup owns
+constexpr int kMaxBase = 16;        // widest unblocked panel (UnBlockedBound, PartialPivLU.h:336)
+
+template <typename T> struct Candidate {
+  T val;    // |a|, or -1 for "no row"
+  int row;  // row index relative to the sub-panel
+};
+
+template <typename T> struct Side {
+  T u[kMaxBase];  // pivot row of the sub-panel after the swap
+  T pivot;
+  int zero;       // the pivot is exactly zero: skip the scaling
+};
+
+template <typename T> __device__ __forceinline__ bool better(T v, int r, T ov, int orow) {
+  return v > ov || (v == ov && r < orow);
+}
+
+// Largest |a| with the smallest row index among ties, over one workgroup.
+template <typename T> __device__ Candidate<T> block_best(T val, int row) {
+  __shared__ T s_val[kRowsPerBlock / 64];
+  __shared__ int s_row[kRowsPerBlock / 64];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const T ov = __shfl_down(val, off, 64);
+    const int orow = __shfl_down(row, off, 64);
+    if (better(ov, orow, val, row)) { val = ov; row = orow; }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { s_val[wave] = val; s_row[wave] = row; }
+  __syncthreads();
+  Candidate<T> c = {s_val[0], s_row[0]};
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+    if (better(s_val[w], s_row[w], c.val, c.row)) { c.val = s_val[w]; c.row = s_row[w]; }
+  return c;
+}
+
+// partials[b] = best candidate of column `col` over rows [row_begin, rows) of block b.
+template <typename T>
+__global__ void lu_colmax(const T* __restrict__ P, int64_t ld, int row_begin, int rows, int col,
+                          Candidate<T>* __restrict__ partials) {
+  const int r = row_begin + blockIdx.x * kRowsPerBlock + threadIdx.x;
+  T val = (T)-1;
+  if (r < rows) val = fabs(P[r + (int64_t)col * ld]);
+  const Candidate<T> c = block_best<T>(val, r);
+  if (threadIdx.x == 0) partials[blockIdx.x] = c;
+}
+
+// One wavefront: pick the pivot of column jj from the per-block candidates, record
+// the transposition, swap the two rows across the sub-panel, publish the pivot row.
+template <typename T>
+__global__ void lu_pivot(T* __restrict__ P, int64_t ld, int jbw, int jj, const Candidate<T>* __restrict__ partials,
+                         int nparts, int* __restrict__ transp, int row_offset, int col_global,
+                         Side<T>* __restrict__ side, int* __restrict__ first_zero, int* __restrict__ nswaps) {
+  const int lane = threadIdx.x;
+  T val = (T)-1;
+  int row = 0x7fffffff;
+  for (int i = lane; i < nparts; i += 64) {
+    const Candidate<T> c = partials[i];
+    if (better(c.val, c.row, val, row)) { val = c.val; row = c.row; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const T ov = __shfl_down(val, off, 64);
+    const int orow = __shfl_down(row, off, 64);
+    if (better(ov, orow, val, row)) { val = ov; row = orow; }
+  }
+  val = __shfl(val, 0, 64);
+  row = __shfl(row, 0, 64);
+  const bool zero = !(val != (T)0);  // exactly zero (or no candidate)
+  if (lane == 0) {
+    transp[0] = row_offset + row;
+    if (zero) {
+      atomicCAS(first_zero, -1, col_global);  // keep the FIRST zero pivot (PartialPivLU.h:391-396)
+    } else if (row != jj) {
+      atomicAdd(nswaps, 1);
+    }
+  }
+  if (lane < jbw) {
+    T top = P[jj + (int64_t)lane * ld];
+    if (!zero && row != jj) {
+      const T other = P[row + (int64_t)lane * ld];
+      P[row + (int64_t)lane * ld] = top;
+      P[jj + (int64_t)lane * ld] = other;
+      top = other;
+    }
+    side->u[lane] = top;
+    if (lane == jj) { side->pivot = top; side->zero = zero ? 1 : 0; }
+  }
+}
+
+// Rows below the pivot: l = a / pivot, rank-1 update of the remaining columns of the
+// sub-panel, and the candidate for the next column's pivot.
+template <typename T>
+__global__ void lu_update(T* __restrict__ P, int64_t ld, int rows, int jbw, int jj, const Side<T>* __restrict__ side,
+                          Candidate<T>* __restrict__ partials) {
+  __shared__ T s_u[kMaxBase];
+  __shared__ T s_pivot;
+  __shared__ int s_zero;
+  if (threadIdx.x < kMaxBase) s_u[threadIdx.x] = side->u[threadIdx.x];
+  if (threadIdx.x == 0) { s_pivot = side->pivot; s_zero = side->zero; }
+  __syncthreads();
+  const int r = jj + 1 + blockIdx.x * kRowsPerBlock + threadIdx.x;
+  T cand = (T)-1;
+  if (r < rows) {
+    T l = P[r + (int64_t)jj * ld];
+    if (!s_zero) {
+      l = l / s_pivot;  // the reference divides (lu.col(k).tail /= pivot, :389)
+      P[r + (int64_t)jj * ld] = l;
+    }
+    for (int c = jj + 1; c < jbw; ++c) {
+      T* dst = P + r + (int64_t)c * ld;
+      const T x = *dst - l * s_u[c];
+      *dst = x;
+      if (c == jj + 1) cand = fabs(x);
+    }
+  }
+  if (jj + 1 < jbw) {
+    const Candidate<T> c = block_best<T>(cand, r);
+    if (threadIdx.x == 0) partials[blockIdx.x] = c;
+  }
+}
+
+// Row transpositions i <-> transp[i], i in [k0, k1), applied in order to `ncols`
+// columns starting at A; one thread per column.  Row indices are global rows of A.
+template <typename T>
+__global__ void lu_laswp(T* __restrict__ A, int64_t ld, int ncols, const int* __restrict__ transp, int k0, int k1) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  T* col = A + (int64_t)c * ld;
+  for (int i = k0; i < k1; ++i) {
+    const int p = transp[i];
+    if (p != i) {
+      const T t = col[i];
+      col[i] = col[p];
+      col[p] = t;
+    }
+  }
+}
+
+// B <- L^-1 B for a unit lower-triangular jb x jb block L (jb <= JB) and jb x ncols B:
+// one thread per column of B, forward substitution in column (saxpy) order.
+template <typename T, int JB>
+__global__ void lu_trsm_small(const T* __restrict__ L, int64_t ldl, T* __restrict__ B, int64_t ldb, int jb, int ncols) {
+  __shared__ T s_l[JB * JB];
+  for (int i = threadIdx.x; i < jb * jb; i += blockDim.x) s_l[(i % jb) + (i / jb) * JB] = L[(i % jb) + (int64_t)(i / jb) * ldl];
+  __syncthreads();
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  T x[JB];
+  T* col = B + (int64_t)c * ldb;
+#pragma unroll
+  for (int i = 0; i < JB; ++i) x[i] = i < jb ? col[i] : (T)0;
+#pragma unroll
+  for (int i = 0; i < JB; ++i) {
+    if (i < jb) {
+#pragma unroll
+      for (int r = i + 1; r < JB; ++r)
+        if (r < jb) x[r] -= s_l[r + i * JB] * x[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < JB; ++i)
+    if (i < jb) col[i] = x[i];
+}
+
+template <typename T> struct KindOf;
+template <> struct KindOf<float> { static constexpr int value = F32; };
+template <> struct KindOf<double> { static constexpr int value = F64; };
+
+template <typename T> hipError_t gemm_minus(int64_t m, int64_t n, int64_t k, const T* A, const T* B, T* C, int64_t ld,
+                                            hipStream_t s) {
+  if (m <= 0 || n <= 0 || k <= 0) return hipSuccess;
+  GemmCall c;
+  c.kind = KindOf<T>::value;
+  c.opa = OP_N; c.opb = OP_N;
+  c.m = m; c.n = n; c.k = k;
+  c.alpha[0] = -1.0; c.alpha[1] = 0.0;
+  c.beta[0] = 1.0; c.beta[1] = 0.0;
+  c.A = A; c.lda = ld;
+  c.B = B; c.ldb = ld;
+  c.C = C; c.ldc = ld;
+  return KindOf<T>::value == F64 ? launch_gemm_f64(c, s) : launch_gemm_f32(c, s);
+}
+
+int block_size_rule(int64_t size, int64_t max_block) {  // PartialPivLU.h:443-448
+  int64_t b = size / 8;
+  b = (b / 16) * 16;
+  return (int)std::min<int64_t>(std::max<int64_t>(b, 8), max_block);
+}
+
+#define LU_TRY(expr)                         \
+  do {                                       \
+    hipError_t e_ = (expr);                  \
+    if (e_ != hipSuccess) return e_;         \
+  } while (0)
+
+template <typename T> struct Workspace {
+  Candidate<T>* partials;
+  Side<T>* side;
+  int* first_zero;
+  int* nswaps;
+};
+
+// unblocked_lu (PartialPivLU.h:357-412) on the rows x jbw sub-panel at P.
+template <typename T>
+hipError_t unblocked(T* P, int64_t ld, int64_t rows, int jbw, int* transp, int row_offset, int col_offset,
+                     const Workspace<T>& w, hipStream_t s) {
+  const int size = (int)std::min<int64_t>(rows, jbw);
+  int nparts = (int)((rows + kRowsPerBlock - 1) / kRowsPerBlock);
+  hipLaunchKernelGGL(lu_colmax<T>, dim3(nparts), dim3(kRowsPerBlock), 0, s, P, ld, 0, (int)rows, 0, w.partials);
+  for (int jj = 0; jj < size; ++jj) {
+    hipLaunchKernelGGL(lu_pivot<T>, dim3(1), dim3(64), 0, s, P, ld, jbw, jj, w.partials, nparts, transp + jj, row_offset,
+                       col_offset + jj, w.side, w.first_zero, w.nswaps);
+    const int64_t below = rows - jj - 1;
+    if (below > 0) {  // (:398) k < rows-1
+      nparts = (int)((below + kRowsPerBlock - 1) / kRowsPerBlock);
+      hipLaunchKernelGGL(lu_update<T>, dim3(nparts), dim3(kRowsPerBlock), 0, s, P, ld, (int)rows, jbw, jj, w.side,
+                         w.partials);
+    }
+  }
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t laswp(T* A, int64_t ld, int64_t ncols, const int* transp, int k0, int k1, hipStream_t s) {
+  if (ncols <= 0 || k1 <= k0) return hipSuccess;
+  hipLaunchKernelGGL(lu_laswp<T>, dim3((unsigned)((ncols + 127) / 128)), dim3(128), 0, s, A, ld, (int)ncols, transp, k0, k1);
+  return hipGetLastError();
+}
+
+// B (bs x ncols) <- L^-1 B with L the unit lower triangle of the bs x bs block at L:
+// 32-row steps of forward substitution, the rows below updated by the GEMM kernel.
+template <typename T>
+hipError_t trsm_unit_lower(const T* L, T* B, int64_t ld, int64_t bs, int64_t ncols, hipStream_t s) {
+  if (ncols <= 0) return hipSuccess;
+  constexpr int JB = 32;
+  for (int64_t j = 0; j < bs; j += JB) {
+    const int jb = (int)std::min<int64_t>(JB, bs - j);
+    hipLaunchKernelGGL((lu_trsm_small<T, JB>), dim3((unsigned)((ncols + 63) / 64)), dim3(64), 0, s, L + j + j * ld, ld,
+                       B + j, ld, jb, (int)ncols);
+    LU_TRY(gemm_minus<T>(bs - j - jb, ncols, jb, L + (j + jb) + j * ld, B + j, B + j + jb, ld, s));
+  }
+  return hipGetLastError();
+}
+
+// blocked_lu (PartialPivLU.h:429-498).  A points at the (row0, row0) corner of the
+// enclosing matrix `base`; transposition entries are written as GLOBAL row indices of
+// `base`, so the caller-level "+= k" of the reference (:481) is already applied.
+template <typename T>
+hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows, int64_t cols, int* transp,
+                   int64_t max_block, const Workspace<T>& w, hipStream_t s) {
+  T* A = base + row0 + col0 * ld;
+  const int64_t size = std::min(rows, cols);
+  if (size <= kMaxBase) {
+    // unblocked_lu works on whole rows.  For a block wider than it is tall, factorise the
+    // leading rows x rows part and bring the columns to its right up to date with the same
+    // operations in the same order: the recorded swaps, then forward substitution.
+    const int jbw = (int)std::min<int64_t>(cols, rows);
+    LU_TRY(unblocked<T>(A, ld, rows, jbw, transp + row0, (int)row0, (int)col0, w, s));
+    if (cols > jbw) {
+      LU_TRY(laswp<T>(base + (col0 + jbw) * ld, ld, cols - jbw, transp, (int)row0, (int)(row0 + jbw), s));
+      hipLaunchKernelGGL((lu_trsm_small<T, kMaxBase>), dim3((unsigned)((cols - jbw + 63) / 64)), dim3(64), 0, s, A, ld,
+                         A + (int64_t)jbw * ld, ld, jbw, (int)(cols - jbw));
+    }
+    return hipGetLastError();
+  }
+  const int64_t block = block_size_rule(size, max_block);
+  for (int64_t k = 0; k < size; k += block) {
+    const int64_t bs = std::min(size - k, block);
+    const int64_t trows = rows - k - bs, tsize = size - k - bs;
+    // the panel [A11; A21], recursively with blocks of 16 (:472-473)
+    LU_TRY(blocked<T>(base, ld, row0 + k, col0 + k, trows + bs, bs, transp, 16, w, s));
+    // transpositions of the panel on the columns to its left inside this level (A_0, :479-483)
+    LU_TRY(laswp<T>(base + col0 * ld, ld, k, transp, (int)(row0 + k), (int)(row0 + k + bs), s));
+    if (trows) {
+      // ... and on the columns to its right (A_2, :488-489)
+      LU_TRY(laswp<T>(base + (col0 + k + bs) * ld, ld, tsize, transp, (int)(row0 + k), (int)(row0 + k + bs), s));
+      T* A11 = A + k + k * ld;
+      T* A12 = A + k + (k + bs) * ld;
+      T* A21 = A + (k + bs) + k * ld;
+      T* A22 = A + (k + bs) + (k + bs) * ld;
+      LU_TRY(trsm_unit_lower<T>(A11, A12, ld, bs, tsize, s));        // (:492)
+      LU_TRY(gemm_minus<T>(trows, tsize, bs, A21, A12, A22, ld, s));  // (:494) the GEMM hot path
+    }
+  }
+  return hipSuccess;
+}
+
+struct LuScratch {
+  std::mutex mu;
+  void* buf = nullptr;
+  size_t cap = 0;
+};
+LuScratch& scratch() {
+  static LuScratch s;
+  return s;
+}
+
+template <typename T>
+hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp, int* first_zero_pivot,
+                          int* nb_transpositions, hipStream_t s) {
+  LuScratch& sc = scratch();
+  std::lock_guard<std::mutex> lock(sc.mu);
+  const size_t nparts = (size_t)((m + kRowsPerBlock - 1) / kRowsPerBlock) + 1;
+  const size_t need = nparts * sizeof(Candidate<T>) + sizeof(Side<T>) + 256;
+  if (need > sc.cap) {
+    if (sc.buf) LU_TRY(hipFree(sc.buf));
+    sc.buf = nullptr;
+    sc.cap = 0;
+    LU_TRY(hipMalloc(&sc.buf, need + 4096));
+    sc.cap = need + 4096;
+  }
+  char* p = static_cast<char*>(sc.buf);
+  Workspace<T> w;
+  w.first_zero = reinterpret_cast<int*>(p);
+  w.nswaps = w.first_zero + 1;
+  w.side = reinterpret_cast<Side<T>*>(p + 64);
+  w.partials = reinterpret_cast<Candidate<T>*>(p + 64 + ((sizeof(Side<T>) + 63) / 64) * 64);
+  LU_TRY(hipMemsetAsync(w.first_zero, 0xFF, sizeof(int), s));  // -1
+  LU_TRY(hipMemsetAsync(w.nswaps, 0, sizeof(int), s));
+  LU_TRY(blocked<T>(A, ld, 0, 0, m, n, d_transp, 256, w, s));
+  int out[2] = {-1, 0};
+  LU_TRY(hipMemcpyAsync(out, w.first_zero, sizeof out, hipMemcpyDeviceToHost, s));
+  LU_TRY(hipStreamSynchronize(s));
+  *first_zero_pivot = out[0];
+  *nb_transpositions = out[1];
+  return hipSuccess;
+}
+
+}  // namespace
+
+hipError_t getrf_device(int kind, int64_t m, int64_t n, void* A, int64_t ld, int* d_transp, int* first_zero_pivot,
+                        int* nb_transpositions, hipStream_t s) {
+  if (kind == F64)
+    return getrf_device_t<double>(m, n, static_cast<double*>(A), ld, d_transp, first_zero_pivot, nb_transpositions, s);
+  if (kind == F32)
+    return getrf_device_t<float>(m, n, static_cast<float*>(A), ld, d_transp, first_zero_pivot, nb_transpositions, s);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace eigamd

@@ -1,0 +1,54 @@
+"""Blocked LU with partial pivoting on the device (eigen_amd/csrc/lu.hip): the host
+mirrors of partial_lu_impl::blocked_lu (Eigen/src/LU/PartialPivLU.h:429-498) and of
+the LAPACK getrf wrapper (lapack/lu.cpp:14-41)."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib
+from .blas import KIND_OF_DTYPE
+
+
+def blocked_lu(a):
+    """In-place LU of the Fortran-ordered float32/float64 array `a` (rows x cols view of a
+    column-major buffer).  Returns (row_transpositions, nb_transpositions,
+    first_zero_pivot) exactly as the reference's blocked_lu reports them."""
+    if a.ndim != 2 or a.strides[0] != a.itemsize:
+        raise ValueError("a must be column-major")
+    kind = KIND_OF_DTYPE[a.dtype]
+    rows, cols = a.shape
+    ld = max(1, a.strides[1] // a.itemsize) if cols > 1 else max(1, rows)
+    transp = np.zeros(max(min(rows, cols), 1), dtype=np.int32)
+    nb, fz = ctypes.c_int(0), ctypes.c_int(-1)
+    rc = lib.eigamd_blocked_lu_host(kind, rows, cols, ctypes.c_void_p(a.ctypes.data), ld,
+                                    ctypes.c_void_p(transp.ctypes.data), ctypes.byref(nb), ctypes.byref(fz))
+    _lib.check(rc, "eigamd_blocked_lu_host")
+    return transp[:min(rows, cols)], nb.value, fz.value
+
+
+def getrf(a):
+    """LAPACK-style ?getrf_ on a Fortran-ordered array: returns (ipiv 1-based, info)."""
+    kind = KIND_OF_DTYPE[a.dtype]
+    fn = {_lib.F32: lib.sgetrf_, _lib.F64: lib.dgetrf_}[kind]
+    m, n = a.shape
+    ld = max(1, a.strides[1] // a.itemsize) if n > 1 else max(1, m)
+    ipiv = np.zeros(max(min(m, n), 1), dtype=np.int32)
+    info = ctypes.c_int(0)
+    fn(ctypes.byref(ctypes.c_int(m)), ctypes.byref(ctypes.c_int(n)), ctypes.c_void_p(a.ctypes.data),
+       ctypes.byref(ctypes.c_int(ld)), ctypes.c_void_p(ipiv.ctypes.data), ctypes.byref(info))
+    return ipiv[:min(m, n)], info.value
+
+
+def getrf_dev(a, stream=None):
+    """In-place LU of a DeviceMatrix.  Returns (transpositions as an int32 cuda tensor,
+    nb_transpositions, first_zero_pivot)."""
+    import torch
+    from .device import _stream_ptr
+    size = min(a.rows, a.cols)
+    transp = torch.zeros(max(size, 1), dtype=torch.int32, device=a.storage.device)
+    nb, fz = ctypes.c_int(0), ctypes.c_int(-1)
+    rc = lib.eigamd_getrf_dev(a.kind, a.rows, a.cols, ctypes.c_void_p(a.ptr), a.ld, ctypes.c_void_p(transp.data_ptr()),
+                              ctypes.byref(fz), ctypes.byref(nb), _stream_ptr(stream))
+    _lib.check(rc, "eigamd_getrf_dev")
+    return transp[:size], nb.value, fz.value

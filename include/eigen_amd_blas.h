@@ -85,6 +85,28 @@ int eigamd_fill_uniform_cyclic_dev(int dtype, void* d_x, int64_t rows, int64_t c
                                    uint64_t seed, int64_t nb_r, int nprow, int myrow, int64_t nb_c,
                                    int npcol, int mycol, void* stream);
 
+/* ---- blocked LU with partial pivoting (real kinds) ----------------------------
+ * The trailing update A22 -= A21*A12 of the blocked factorisation is the GEMM path.
+ *
+ * eigamd_blocked_lu_host replaces partial_lu_impl<Scalar,ColMajor,int>::blocked_lu
+ * (Eigen/src/LU/PartialPivLU.h:429-498; the seam Eigen/src/LU/PartialPivLU_LAPACKE.h:46-66
+ * uses): in-place factors, 0-based row transpositions (row i was swapped with row
+ * row_transpositions[i]), the number of actual swaps, and through *first_zero_pivot
+ * the index of the first exactly-zero pivot or -1.  Same block-size rule, recursion
+ * and pivot choice as the reference, so pivots match Eigen's.
+ *
+ * dgetrf_/sgetrf_ replace EIGEN_LAPACK_FUNC(getrf) (lapack/lu.cpp:14-41): 1-based
+ * ipiv, info = -i for a bad argument i (through xerbla_), else first zero pivot + 1.
+ *
+ * eigamd_getrf_dev factorises a matrix already in HBM; d_transp is device memory
+ * (min(m,n) ints).  It synchronises `stream` before returning the two counters. */
+int eigamd_blocked_lu_host(int dtype, int64_t rows, int64_t cols, void* lu, int64_t lu_stride,
+                           int* row_transpositions, int* nb_transpositions, int* first_zero_pivot);
+int dgetrf_(const int* m, const int* n, double* a, const int* lda, int* ipiv, int* info);
+int sgetrf_(const int* m, const int* n, float* a, const int* lda, int* ipiv, int* info);
+int eigamd_getrf_dev(int dtype, int64_t m, int64_t n, void* d_a, int64_t lda, int* d_transp,
+                     int* first_zero_pivot, int* nb_transpositions, void* stream);
+
 /* ---- misc --------------------------------------------------------------------- */
 const char* eigamd_last_error(void);  /* text of the last failure on this thread */
 int eigamd_device_ok(void);           /* 1 if a gfx950 device is usable, else 0 */

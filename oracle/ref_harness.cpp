@@ -110,30 +110,20 @@ double ref_bench_gemm(int dtype, int64_t m, int64_t n, int64_t k, int tries) {
   return -1;
 }
 
-// PartialPivLU on a column-major double matrix, in place
-// (Eigen/src/LU/PartialPivLU.h:503-546).  piv[i] = row swapped with row i (0-based,
-// the transpositions Eigen records).  Returns 0.
-int ref_partial_piv_lu(int64_t n, double* a, int64_t lda, int* piv) {
-  typedef Matrix<double, Dynamic, Dynamic, ColMajor> Mat;
-  Map<Mat, 0, OuterStride<> > A(a, n, n, OuterStride<>(lda));
-  PartialPivLU<Mat> lu(A);
-  A = lu.matrixLU();
-  const auto& tr = lu.permutationP().indices();  // permutation, not transpositions
-  // Recover the transposition sequence from the permutation P (P*A = L*U).
-  std::vector<int> perm(n), pos(n);
-  for (int64_t i = 0; i < n; ++i) { perm[i] = (int)i; pos[i] = (int)i; }
-  // P applied to A moves row p(i) ... : indices()[i] = destination of row i.
-  std::vector<int> src(n);
-  for (int64_t i = 0; i < n; ++i) src[tr[i]] = (int)i;  // row i of P*A is row src[i] of A
-  for (int64_t i = 0; i < n; ++i) {
-    const int want = src[i];       // original row that must land at i
-    const int at = pos[want];      // where it currently sits
-    piv[i] = at;
-    const int other = perm[i];
-    perm[at] = other; pos[other] = at;
-    perm[i] = want; pos[want] = (int)i;
-  }
-  return 0;
+// partial_lu_impl::blocked_lu itself (Eigen/src/LU/PartialPivLU.h:429-498): in-place
+// factors, 0-based row transpositions, number of transpositions; returns the index
+// of the first exactly-zero pivot or -1.
+long ref_blocked_lu_d(int64_t rows, int64_t cols, double* a, int64_t lda, int* transp, int* nb_transp) {
+  int nb = 0;
+  Index r = internal::partial_lu_impl<double, ColMajor, int>::blocked_lu(rows, cols, a, lda, transp, nb);
+  *nb_transp = nb;
+  return (long)r;
+}
+long ref_blocked_lu_s(int64_t rows, int64_t cols, float* a, int64_t lda, int* transp, int* nb_transp) {
+  int nb = 0;
+  Index r = internal::partial_lu_impl<float, ColMajor, int>::blocked_lu(rows, cols, a, lda, transp, nb);
+  *nb_transp = nb;
+  return (long)r;
 }
 
 double ref_bench_lu(int64_t n, int tries) {
