@@ -1,0 +1,89 @@
+// Header-level seam: routes Eigen's dense product kernel and its blocked
+// PartialPivLU to libeigen_amd_blas.so without enabling EIGEN_USE_BLAS /
+// EIGEN_USE_LAPACKE (which also reroute gemv, trsm, symm, Cholesky, QR, ...).
+//
+//   #include <Eigen/Core>
+//   #include <Eigen/LU>
+//   #include <eigen_amd/EigenSeam.h>     // after the Eigen headers, before any product is instantiated
+//
+// It adds the two partial specialisations the reference itself adds for external
+// back ends -- general_matrix_matrix_product<Index,T,LhsOrder,ConjLhs,T,RhsOrder,ConjRhs,ColMajor,1>
+// (Eigen/src/Core/products/GeneralMatrixMatrix_BLAS.h:56-108) and
+// partial_lu_impl<T,StorageOrder,int> (Eigen/src/LU/PartialPivLU_LAPACKE.h:44-79) --
+// forwarding to the 64-bit C entry points.  Unlike the F77 route, a conjugated
+// column-major operand needs no temporary (EIGAMD_OP_CONJ).
+#ifndef EIGEN_AMD_EIGEN_SEAM_H
+#define EIGEN_AMD_EIGEN_SEAM_H
+
+#ifdef EIGEN_USE_BLAS
+#error "eigen_amd/EigenSeam.h replaces EIGEN_USE_BLAS for the product path; define only one of them"
+#endif
+
+#include <complex>
+#include <cstdio>
+#include <cstdlib>
+
+#include "../eigen_amd_blas.h"
+
+namespace Eigen {
+namespace internal {
+
+template <typename T> struct eigamd_kind;
+template <> struct eigamd_kind<float> { enum { value = EIGAMD_F32 }; };
+template <> struct eigamd_kind<double> { enum { value = EIGAMD_F64 }; };
+template <> struct eigamd_kind<std::complex<float> > { enum { value = EIGAMD_C32 }; };
+template <> struct eigamd_kind<std::complex<double> > { enum { value = EIGAMD_C64 }; };
+
+inline void eigamd_require(int rc, const char* what) {
+  if (rc != EIGAMD_OK) {
+    std::fprintf(stderr, "eigen_amd: %s failed (%d): %s\n", what, rc, eigamd_last_error());
+    std::abort();
+  }
+}
+
+template <typename Index, typename T, int LhsOrder, bool ConjLhs, int RhsOrder, bool ConjRhs>
+struct eigamd_product {
+  typedef gebp_traits<T, T> Traits;  // read by gemm_functor and parallelize_gemm
+  static void run(Index rows, Index cols, Index depth, const T* lhs, Index lhsStride, const T* rhs, Index rhsStride,
+                  T* res, Index resIncr, Index resStride, T alpha, level3_blocking<T, T>&, GemmParallelInfo<Index>*) {
+    eigen_assert(resIncr == 1);
+    EIGEN_ONLY_USED_FOR_DEBUG(resIncr);
+    const int opa = LhsOrder == RowMajor ? (ConjLhs ? EIGAMD_OP_C : EIGAMD_OP_T) : (ConjLhs ? EIGAMD_OP_CONJ : EIGAMD_OP_N);
+    const int opb = RhsOrder == RowMajor ? (ConjRhs ? EIGAMD_OP_C : EIGAMD_OP_T) : (ConjRhs ? EIGAMD_OP_CONJ : EIGAMD_OP_N);
+    const T one(1);
+    eigamd_require(eigamd_gemm_host(eigamd_kind<T>::value, opa, opb, rows, cols, depth, &alpha, lhs, lhsStride, rhs,
+                                    rhsStride, &one, res, resStride),
+                   "eigamd_gemm_host");
+  }
+};
+
+#define EIGAMD_PRODUCT_SEAM(T)                                                                            \
+  template <typename Index, int LhsOrder, bool ConjLhs, int RhsOrder, bool ConjRhs>                       \
+  struct general_matrix_matrix_product<Index, T, LhsOrder, ConjLhs, T, RhsOrder, ConjRhs, ColMajor, 1>     \
+      : eigamd_product<Index, T, LhsOrder, ConjLhs, RhsOrder, ConjRhs> {};
+EIGAMD_PRODUCT_SEAM(float)
+EIGAMD_PRODUCT_SEAM(double)
+EIGAMD_PRODUCT_SEAM(std::complex<float>)
+EIGAMD_PRODUCT_SEAM(std::complex<double>)
+#undef EIGAMD_PRODUCT_SEAM
+
+#ifdef EIGEN_PARTIALLU_H
+template <typename T> struct eigamd_lu {
+  static Index blocked_lu(Index rows, Index cols, T* lu_data, Index luStride, int* row_transpositions,
+                          int& nb_transpositions, Index /*maxBlockSize*/ = 256) {
+    int first_zero = -1, nb = 0;
+    eigamd_require(eigamd_blocked_lu_host(eigamd_kind<T>::value, rows, cols, lu_data, luStride, row_transpositions, &nb,
+                                          &first_zero),
+                   "eigamd_blocked_lu_host");
+    nb_transpositions = nb;
+    return first_zero;
+  }
+};
+template <> struct partial_lu_impl<double, ColMajor, int> : eigamd_lu<double> {};
+template <> struct partial_lu_impl<float, ColMajor, int> : eigamd_lu<float> {};
+#endif
+
+}  // namespace internal
+}  // namespace Eigen
+
+#endif  // EIGEN_AMD_EIGEN_SEAM_H
