@@ -153,6 +153,39 @@ def side_measurement(dtype, n, steps):
     return round(flops / best / 1e9, 2)
 
 
+def lu_measurement(n):
+    """PartialPivLU-equivalent factorisation (eigamd_getrf_dev) of an n x n double matrix
+    resident in HBM; 2/3 n^3 flop.  The trailing updates run on the GEMM kernel."""
+    import torch
+    import eigen_amd
+    from eigen_amd.device import DeviceMatrix
+    from eigen_amd import lu as ealu
+    a = DeviceMatrix(n, n, eigen_amd.F64)
+    best = 1e30
+    for _ in range(2):
+        a.fill_uniform(77)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, _, first_zero = ealu.getrf_dev(a)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    return {f"lu_{n}_f64_seconds": round(best, 4), f"lu_{n}_f64_tflops": round(2.0 / 3.0 * n ** 3 / best / 1e12, 2)}
+
+
+def measured_traffic(dtype, n):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC
+    passes (FETCH_SIZE doubled as gfx950 requires, plus WRITE_SIZE); None when no
+    measurement for this workload is on file."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+        entry = table.get(f"{dtype}_{n}")
+        return (entry["bytes_per_launch"], entry["source"]) if entry else (None, None)
+    except (OSError, ValueError, KeyError):
+        return (None, None)
+
+
 def main():
     args = parse()
     import numpy as np
@@ -270,8 +303,11 @@ def main():
             "parity_max_test_ratio": round(ratio, 3),
             "parity_limit": 16.0,
             "roofline": {"bound": "mfma", "achieved": round(kernel_tflops, 3), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(kernel_tflops / peak, 4), "traffic": None,
-                         "kernel": "eigamd::gemm_kernel<F64, A m-contiguous, B k-contiguous>",
+                         "frac": round(kernel_tflops / peak, 4), "traffic": measured_traffic(args.dtype, n)[0],
+                         "traffic_source": measured_traffic(args.dtype, n)[1],
+                         "kernel": f"eigamd::gemm_kernel<{args.dtype}, A m-contiguous, B k-contiguous>",
+                         "algorithmic_bytes_per_launch": 4.0 * n * n * {"f32": 4, "f64": 8, "c32": 8, "c64": 16}[args.dtype]
+                         if world == 1 else None,
                          "launches": len(ms), "avg_launch_ms": round(sum(ms) / max(len(ms), 1), 4),
                          "flops_per_launch": fl[0] if fl else 0},
         }
@@ -282,6 +318,7 @@ def main():
                     "zgemm_8192_tflops": side_measurement("c64", 8192, 3),
                     "cgemm_8192_tflops": side_measurement("c32", 8192, 3),
                 }
+                out["extra"].update(lu_measurement(32768))
                 out["extra"]["sgemm_pct_of_peak"] = round(100 * out["extra"]["sgemm_16384_tflops"] / PEAK_TFLOPS["f32"], 2)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args)

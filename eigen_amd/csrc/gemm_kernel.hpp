@@ -47,7 +47,30 @@ struct GemmParams {
   int xcd_remap;          // 1: give each XCD a contiguous run of the tile sequence
 };
 
-constexpr int kThreads = 256;  // 4 wavefronts, 2 x 2 over the block tile
+// Tile geometry per scalar kind.  WM x WN wavefronts per workgroup, each owning
+// MT x NT MFMA tiles; BK is the k extent of one LDS stage (128 bytes of k for the
+// K-contiguous operand).  The EIGAMD_* macros exist so that profiling builds can try
+// other shapes (tools/build_variant.sh); the defaults are the shipped configuration.
+// Shape = WM, WN, MT, NT, BK, workgroups per CU the register budget is sized for,
+// and whether the fragments of k-step ks+1 are read explicitly ahead of the MFMAs of
+// k-step ks (1) or the order is left to the compiler's scheduler (0).
+#ifndef EIGAMD_F64_SHAPE
+#define EIGAMD_F64_SHAPE 2, 2, 4, 4, 16, 2, 0
+#endif
+#ifndef EIGAMD_F32_SHAPE
+#define EIGAMD_F32_SHAPE 2, 4, 4, 2, 32, 1, 1
+#endif
+#ifndef EIGAMD_C64_SHAPE
+#define EIGAMD_C64_SHAPE 2, 2, 4, 2, 8, 2, 1
+#endif
+#ifndef EIGAMD_C32_SHAPE
+#define EIGAMD_C32_SHAPE 2, 2, 2, 2, 16, 2, 1
+#endif
+
+template <int WM_, int WN_, int MT_, int NT_, int BK_, int PER_CU_, int PREFETCH_> struct Shape {
+  static constexpr int WM = WM_, WN = WN_, MT = MT_, NT = NT_, BK = BK_, PER_CU = PER_CU_;
+  static constexpr bool PREFETCH = PREFETCH_ != 0;
+};
 
 template <int KIND> struct Traits;
 
@@ -56,9 +79,9 @@ template <> struct Traits<F32> {
   typedef float Real;
   typedef f16_t Acc;
   static constexpr bool kCplx = false;
+  typedef Shape<EIGAMD_F32_SHAPE> S;
   static constexpr int TM = 32, KS = 2, NACC = 16;  // v_mfma_f32_32x32x2_f32
-  static constexpr int MT = 2, NT = 2;              // MFMA tiles per wave (m, n)
-  static constexpr int BK = 32;
+  static constexpr int WM = S::WM, WN = S::WN, MT = S::MT, NT = S::NT, BK = S::BK;
   static constexpr int PADX = 0, PADK = 1;
   static constexpr bool kVecWriteK = false;  // odd pitch: element-wise LDS writes
 };
@@ -67,9 +90,9 @@ template <> struct Traits<F64> {
   typedef double Real;
   typedef d4_t Acc;
   static constexpr bool kCplx = false;
+  typedef Shape<EIGAMD_F64_SHAPE> S;
   static constexpr int TM = 16, KS = 4, NACC = 4;  // v_mfma_f64_16x16x4_f64
-  static constexpr int MT = 4, NT = 4;
-  static constexpr int BK = 16;
+  static constexpr int WM = S::WM, WN = S::WN, MT = S::MT, NT = S::NT, BK = S::BK;
   static constexpr int PADX = 16, PADK = 2;
   static constexpr bool kVecWriteK = true;
 };
@@ -78,9 +101,9 @@ template <> struct Traits<C32> {
   typedef float Real;
   typedef f16_t Acc;
   static constexpr bool kCplx = true;
+  typedef Shape<EIGAMD_C32_SHAPE> S;
   static constexpr int TM = 32, KS = 2, NACC = 16;
-  static constexpr int MT = 2, NT = 2;
-  static constexpr int BK = 16;
+  static constexpr int WM = S::WM, WN = S::WN, MT = S::MT, NT = S::NT, BK = S::BK;
   static constexpr int PADX = 0, PADK = 1;
   static constexpr bool kVecWriteK = false;
 };
@@ -89,17 +112,19 @@ template <> struct Traits<C64> {
   typedef double Real;
   typedef d4_t Acc;
   static constexpr bool kCplx = true;
+  typedef Shape<EIGAMD_C64_SHAPE> S;
   static constexpr int TM = 16, KS = 4, NACC = 4;
-  static constexpr int MT = 4, NT = 2;
-  static constexpr int BK = 8;
+  static constexpr int WM = S::WM, WN = S::WN, MT = S::MT, NT = S::NT, BK = S::BK;
   static constexpr int PADX = 0, PADK = 2;
   static constexpr bool kVecWriteK = true;
 };
 
 template <int KIND> struct Geometry {
   typedef Traits<KIND> T;
-  static constexpr int BM = 2 * T::MT * T::TM;
-  static constexpr int BN = 2 * T::NT * T::TM;
+  static constexpr int BM = T::WM * T::MT * T::TM;
+  static constexpr int BN = T::WN * T::NT * T::TM;
+  static constexpr int THREADS = 64 * T::WM * T::WN;
+  static constexpr int MIN_WAVES_PER_SIMD = T::S::PER_CU * THREADS / 256;
   static constexpr int BK = T::BK;
   static constexpr int ES = sizeof(typename T::Elem);
   static constexpr int EPC = 16 / ES;  // elements per 16-byte chunk
@@ -138,6 +163,7 @@ template <int KIND, bool KC, int BX> struct TileIO {
   typedef Traits<KIND> T;
   typedef Geometry<KIND> G;
   typedef typename T::Elem Elem;
+  static constexpr int kThreads = G::THREADS;
   static constexpr int BK = T::BK;
   static constexpr int EPC = G::EPC;
   static constexpr int PITCH = KC ? (BK + T::PADK) : (BX + T::PADX);
@@ -204,7 +230,8 @@ template <int KIND, bool KC, int BX> struct TileIO {
 };
 
 template <int KIND, bool AK, bool BKC, bool GUARD>
-__global__ void __launch_bounds__(kThreads, 2) gemm_kernel(const GemmParams p) {
+__global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_WAVES_PER_SIMD)
+    gemm_kernel(const GemmParams p) {
   typedef Traits<KIND> T;
   typedef Geometry<KIND> G;
   typedef typename T::Elem Elem;
@@ -212,6 +239,7 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(const GemmParams p) {
   typedef typename T::Acc Acc;
   constexpr int BM = G::BM, BN = G::BN, BK = G::BK;
   constexpr int TM = T::TM, KS = T::KS, MT = T::MT, NT = T::NT;
+  constexpr int NPLANE = T::kCplx ? 2 : 1;
   typedef TileIO<KIND, AK, BM> IOA;
   typedef TileIO<KIND, BKC, BN> IOB;
   constexpr int LDS_A = G::lds_elems(AK, BM);
@@ -224,12 +252,12 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(const GemmParams p) {
   const int wave = tid >> 6;
   const int xi = lane % TM;
   const int kk = lane / TM;
-  const int wm0 = (wave & 1) * (MT * TM);
-  const int wn0 = (wave >> 1) * (NT * TM);
+  const int wm0 = (wave % T::WM) * (MT * TM);
+  const int wn0 = (wave / T::WM) * (NT * TM);
 
   // Block -> tile mapping.  Consecutive block ids are dealt round-robin over
   // the 8 XCDs; give each XCD a contiguous run of the tile sequence, and walk
-  // the sequence in groups of 8 tile rows so that co-resident blocks of one
+  // the sequence in groups of tile rows so that co-resident blocks of one
   // XCD share A and B panels in that XCD's L2.
   int tile_m, tile_n;
   {
@@ -264,13 +292,13 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(const GemmParams p) {
 
   uint4 ra[IOA::NCHUNK], rb[IOB::NCHUNK];
 
-  Acc acc[NT][MT][T::kCplx ? 2 : 1];
+  Acc acc[NT][MT][NPLANE];
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int c = 0; c < (T::kCplx ? 2 : 1); ++c)
+      for (int c = 0; c < NPLANE; ++c)
 #pragma unroll
         for (int r = 0; r < T::NACC; ++r) acc[j][i][c][r] = 0;
 
@@ -303,24 +331,47 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(const GemmParams p) {
   }
   __syncthreads();
 
+  // Per-lane fragment origins inside a stage.
+  const int fa0 = IOA::frag_index(wm0 + xi, kk);
+  const int fb0 = IOB::frag_index(wn0 + xi, kk);
+  constexpr int KSTEPS = BK / KS;
+
   for (int t = 0; t < ntiles; ++t) {
-    const Elem* sa = smem + (t & 1) * (LDS_A + LDS_B);
-    const Elem* sb = sa + LDS_A;
+    const Elem* sa = smem + (t & 1) * (LDS_A + LDS_B) + fa0;
+    const Elem* sb = smem + (t & 1) * (LDS_A + LDS_B) + LDS_A + fb0;
     const bool more = t + 1 < ntiles;
     if (more) gload(t + 1);
 
+    // With PREFETCH the fragments of k-step ks+1 are read while the MFMAs of k-step ks
+    // issue; without it each k-step reads its own fragments and the compiler interleaves.
+    Elem fa[2][MT], fb[2][NT];
+    if constexpr (T::S::PREFETCH) {
 #pragma unroll
-    for (int ks = 0; ks < BK / KS; ++ks) {
-      Elem fa[MT], fb[NT];
+      for (int i = 0; i < MT; ++i) fa[0][i] = sa[IOA::frag_index(i * TM, 0)];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) fa[i] = sa[IOA::frag_index(wm0 + i * TM + xi, ks * KS + kk)];
+      for (int j = 0; j < NT; ++j) fb[0][j] = sb[IOB::frag_index(j * TM, 0)];
+    }
 #pragma unroll
-      for (int j = 0; j < NT; ++j) fb[j] = sb[IOB::frag_index(wn0 + j * TM + xi, ks * KS + kk)];
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int cur = T::S::PREFETCH ? (ks & 1) : 0, nxt = cur ^ 1;
+      if constexpr (T::S::PREFETCH) {
+        if (ks + 1 < KSTEPS) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i) fa[nxt][i] = sa[IOA::frag_index(i * TM, (ks + 1) * KS)];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) fb[nxt][j] = sb[IOB::frag_index(j * TM, (ks + 1) * KS)];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[0][i] = sa[IOA::frag_index(i * TM, ks * KS)];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[0][j] = sb[IOB::frag_index(j * TM, ks * KS)];
+      }
       if constexpr (!T::kCplx) {
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-          for (int i = 0; i < MT; ++i) mma(acc[j][i][0], fb[j], fa[i]);
+          for (int i = 0; i < MT; ++i) mma(acc[j][i][0], fb[cur][j], fa[cur][i]);
       } else {
         // With sa, sb = -1 for a conjugated operand and +1 otherwise:
         //   Re += br*ar - (sa*sb) * bi*ai
@@ -328,15 +379,15 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(const GemmParams p) {
         // so one sign flip of bi per accumulator covers all four cases.
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          const Real br = fb[j].x, bi = fb[j].y;
+          const Real br = fb[cur][j].x, bi = fb[cur][j].y;
           const Real bi_r = flip(bi, mask_r);
           const Real bi_i = flip(bi, mask_i);
 #pragma unroll
           for (int i = 0; i < MT; ++i) {
-            mma(acc[j][i][0], br, fa[i].x);
-            mma(acc[j][i][1], br, fa[i].y);
-            mma(acc[j][i][0], bi_r, fa[i].y);
-            mma(acc[j][i][1], bi_i, fa[i].x);
+            mma(acc[j][i][0], br, fa[cur][i].x);
+            mma(acc[j][i][1], br, fa[cur][i].y);
+            mma(acc[j][i][0], bi_r, fa[cur][i].y);
+            mma(acc[j][i][1], bi_i, fa[cur][i].x);
           }
         }
       }
@@ -351,54 +402,47 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(const GemmParams p) {
   }
 
   // Epilogue: C = alpha * acc + beta * C.  beta == 0 never reads C
-  // (blas/level3_impl.h:64: NaN/Inf in C must not propagate).
-  Elem* __restrict__ C = static_cast<Elem*>(p.C);
-  if constexpr (!T::kCplx) {
-    const Real alpha = (Real)p.alpha[0], beta = (Real)p.beta[0];
-    const bool use_c = p.beta[0] != 0.0;
+  // (blas/level3_impl.h:64: NaN/Inf in C must not propagate).  Per column group j the
+  // loads of C are issued together, then combined and stored.
+  const bool use_c = p.beta[0] != 0.0 || p.beta[1] != 0.0;
+  const int mrow = wm0 + xi;                       // + i * TM
+  const int nrow = wn0 + acc_row<KIND>(0, kk);     // + j * TM + acc_row(r, 0)
+  Elem* __restrict__ cbase = static_cast<Elem*>(p.C) + (int64_t)(m0 + mrow) + (int64_t)(n0 + nrow) * p.ldc;
+  const Real alr = (Real)p.alpha[0], ali = (Real)p.alpha[1];
+  const Real ber = (Real)p.beta[0], bei = (Real)p.beta[1];
+  const Real sgn = p.conj_a ? (Real)-1 : (Real)1;
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+  for (int j = 0; j < NT; ++j) {
+    Elem cv[MT][T::NACC];
+    if (use_c) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int m = wm0 + i * TM + xi;
-#pragma unroll
-        for (int r = 0; r < T::NACC; ++r) {
-          const int n = wn0 + j * TM + acc_row<KIND>(r, kk);
-          if (!GUARD || (m < mrem && n < nrem)) {
-            Elem* dst = C + (int64_t)(m0 + m) + (int64_t)(n0 + n) * p.ldc;
-            Real v = alpha * acc[j][i][0][r];
-            if (use_c) v = fma(beta, *dst, v);
-            *dst = v;
-          }
-        }
-      }
-  } else {
-    const Real ar = (Real)p.alpha[0], ai = (Real)p.alpha[1];
-    const Real br = (Real)p.beta[0], bi = (Real)p.beta[1];
-    const bool use_c = p.beta[0] != 0.0 || p.beta[1] != 0.0;
-    const Real sgn = p.conj_a ? (Real)-1 : (Real)1;
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int m = wm0 + i * TM + xi;
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int r = 0; r < T::NACC; ++r) {
-          const int n = wn0 + j * TM + acc_row<KIND>(r, kk);
-          if (!GUARD || (m < mrem && n < nrem)) {
-            Elem* dst = C + (int64_t)(m0 + m) + (int64_t)(n0 + n) * p.ldc;
-            const Real pr = acc[j][i][0][r], pi = sgn * acc[j][i][1][r];
-            Elem v;
-            v.x = ar * pr - ai * pi;
-            v.y = ar * pi + ai * pr;
-            if (use_c) {
-              const Elem c = *dst;
-              v.x += br * c.x - bi * c.y;
-              v.y += br * c.y + bi * c.x;
-            }
-            *dst = v;
+          const int nn = j * TM + acc_row<KIND>(r, 0);
+          Elem z = {};
+          cv[i][r] = (!GUARD || (mrow + i * TM < mrem && nrow + nn < nrem)) ? cbase[i * TM + (int64_t)nn * p.ldc] : z;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < T::NACC; ++r) {
+        const int nn = j * TM + acc_row<KIND>(r, 0);
+        Elem v;
+        if constexpr (!T::kCplx) {
+          v = alr * acc[j][i][0][r];
+          if (use_c) v = fma(ber, cv[i][r], v);
+        } else {
+          const Real pr = acc[j][i][0][r], pi = sgn * acc[j][i][1][r];
+          v.x = alr * pr - ali * pi;
+          v.y = alr * pi + ali * pr;
+          if (use_c) {
+            v.x += ber * cv[i][r].x - bei * cv[i][r].y;
+            v.y += ber * cv[i][r].y + bei * cv[i][r].x;
           }
         }
+        if (!GUARD || (mrow + i * TM < mrem && nrow + nn < nrem)) cbase[i * TM + (int64_t)nn * p.ldc] = v;
       }
   }
 }

@@ -71,7 +71,7 @@ static hipError_t launch_region(const GemmCall& c, int64_t r0, int64_t c0, int64
   p.xcd_remap = tuning().xcd_remap;
   const int64_t nblk = (int64_t)p.tiles_m * p.tiles_n;
   if (nblk > 0x7fffffff) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((gemm_kernel<KIND, AK, BKC, GUARD>), dim3((unsigned)nblk), dim3(kThreads),
+  hipLaunchKernelGGL((gemm_kernel<KIND, AK, BKC, GUARD>), dim3((unsigned)nblk), dim3(G::THREADS),
                      tuning().extra_lds, stream, p);
   return hipGetLastError();
 }

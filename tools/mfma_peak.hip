@@ -10,7 +10,7 @@ template <int NACC> __global__ void __launch_bounds__(256) peak_f64(double* out,
   double a = a0 + threadIdx.x * 1e-3, b = b0 - threadIdx.x * 1e-3;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < NACC; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    for (int i = 0; i < NACC; i++) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
   }
   double s = 0; for (int i = 0; i < NACC; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
@@ -20,7 +20,7 @@ template <int NACC> __global__ void __launch_bounds__(256) peak_f32(float* out, 
   float a = a0 + threadIdx.x * 1e-3f, b = b0 - threadIdx.x * 1e-3f;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < NACC; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    for (int i = 0; i < NACC; i++) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
   }
   float s = 0; for (int i = 0; i < NACC; i++) for (int r = 0; r < 16; r++) s += acc[i][r];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
