@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the sgemm / complex side measurements")
     ap.add_argument("--cpu-size", type=int, default=8192)
+    ap.add_argument("--lu", type=int, default=0, metavar="N",
+                    help="with >1 GPU: also time the distributed LU of an N x N double matrix (extra key)")
     return ap.parse_args()
 
 
@@ -278,6 +280,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ratio = float(t.item())
 
+    lu_extra = None
+    if world > 1 and args.lu:
+        from eigen_amd.plu import ColCyclicMatrix, lu_block_size, pgetrf
+        L = ColCyclicMatrix(args.lu, lu_block_size(args.lu), KIND["f64"]).fill_uniform(77)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        _, _, fz = pgetrf(L)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        lu_extra = {f"lu_{args.lu}_f64_seconds": round(float(t.item()), 4),
+                    f"lu_{args.lu}_f64_tflops": round(2.0 / 3.0 * args.lu ** 3 / float(t.item()) / 1e12, 2),
+                    "lu_layout": f"1-D column block-cyclic over {world} GPUs, block {lu_block_size(args.lu)}"}
+
     ms, fl = timed.summary()
     kernel_tflops = sum(fl) / (sum(ms) * 1e-3) / 1e12 if ms else 0.0
     peak = PEAK_TFLOPS[args.dtype]
@@ -311,6 +329,8 @@ def main():
                          "launches": len(ms), "avg_launch_ms": round(sum(ms) / max(len(ms), 1), 4),
                          "flops_per_launch": fl[0] if fl else 0},
         }
+        if lu_extra:
+            out["extra"] = lu_extra
         if world == 1:
             if not args.no_extra:
                 out["extra"] = {

@@ -308,7 +308,7 @@ int eigamd_fill_uniform_host(int dtype, void* x, int64_t rows, int64_t cols, int
 }
 
 int eigamd_getrf_dev(int dtype, int64_t m, int64_t n, void* d_a, int64_t lda, int* d_transp,
-                     int* first_zero_pivot, int* nb_transpositions, void* stream) {
+                     int64_t max_block_size, int* first_zero_pivot, int* nb_transpositions, void* stream) {
   if (dtype != F32 && dtype != F64) return fail(EIGAMD_ERR_ARG, "LU supports the real kinds (f32, f64)");
   if (m < 0 || n < 0 || lda < std::max<int64_t>(1, m) || m > 0x7fffffff || n > 0x7fffffff)
     return fail(EIGAMD_ERR_ARG, "invalid LU arguments");
@@ -316,10 +316,33 @@ int eigamd_getrf_dev(int dtype, int64_t m, int64_t n, void* d_a, int64_t lda, in
   if (m > 0 && n > 0) {
     int rc = ensure_device();
     if (rc != EIGAMD_OK) return rc;
-    HIP_TRY(getrf_device(dtype, m, n, d_a, lda, d_transp, &fz, &nb, static_cast<hipStream_t>(stream)));
+    HIP_TRY(getrf_device(dtype, m, n, d_a, lda, d_transp, max_block_size, &fz, &nb, static_cast<hipStream_t>(stream)));
   }
   if (first_zero_pivot) *first_zero_pivot = fz;
   if (nb_transpositions) *nb_transpositions = nb;
+  return EIGAMD_OK;
+}
+
+int eigamd_laswp_dev(int dtype, void* d_a, int64_t lda, int64_t ncols, const int* d_transp, int k0, int k1,
+                     void* stream) {
+  if ((dtype != F32 && dtype != F64) || lda < 1 || ncols < 0 || k0 < 0 || k1 < k0)
+    return fail(EIGAMD_ERR_ARG, "invalid laswp arguments");
+  if (ncols == 0 || k1 == k0) return EIGAMD_OK;
+  int rc = ensure_device();
+  if (rc != EIGAMD_OK) return rc;
+  HIP_TRY(laswp_device(dtype, d_a, lda, ncols, d_transp, k0, k1, static_cast<hipStream_t>(stream)));
+  return EIGAMD_OK;
+}
+
+int eigamd_trsm_llnu_dev(int dtype, int64_t m, int64_t n, const void* d_l, int64_t ldl, void* d_b, int64_t ldb,
+                         void* stream) {
+  if ((dtype != F32 && dtype != F64) || m < 0 || n < 0 || ldl < std::max<int64_t>(1, m) ||
+      ldb < std::max<int64_t>(1, m))
+    return fail(EIGAMD_ERR_ARG, "invalid trsm arguments");
+  if (m == 0 || n == 0) return EIGAMD_OK;
+  int rc = ensure_device();
+  if (rc != EIGAMD_OK) return rc;
+  HIP_TRY(trsm_llnu_device(dtype, m, n, d_l, ldl, d_b, ldb, static_cast<hipStream_t>(stream)));
   return EIGAMD_OK;
 }
 
@@ -342,7 +365,7 @@ static int lu_host_impl(int dtype, int64_t m, int64_t n, void* a, int64_t lda, i
   if ((rc = st.reserve(2, (size_t)dld * n * es)) != EIGAMD_OK) return rc;
   if ((rc = st.reserve(0, (size_t)size * sizeof(int) + 64)) != EIGAMD_OK) return rc;
   HIP_TRY(hipMemcpy2DAsync(st.buf[2], dld * es, a, lda * es, m * es, n, hipMemcpyHostToDevice, st.stream));
-  HIP_TRY(getrf_device(dtype, m, n, st.buf[2], dld, static_cast<int*>(st.buf[0]), first_zero_pivot,
+  HIP_TRY(getrf_device(dtype, m, n, st.buf[2], dld, static_cast<int*>(st.buf[0]), 256, first_zero_pivot,
                        nb_transpositions, st.stream));
   HIP_TRY(hipMemcpy2DAsync(a, lda * es, st.buf[2], dld * es, m * es, n, hipMemcpyDeviceToHost, st.stream));
   HIP_TRY(hipMemcpyAsync(transp, st.buf[0], (size_t)size * sizeof(int), hipMemcpyDeviceToHost, st.stream));

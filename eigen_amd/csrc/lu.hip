@@ -193,8 +193,16 @@ template <typename T> struct KindOf;
 template <> struct KindOf<float> { static constexpr int value = F32; };
 template <> struct KindOf<double> { static constexpr int value = F64; };
 
+template <typename T> hipError_t gemm_minus3(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B,
+                                             int64_t ldb, T* C, int64_t ldc, hipStream_t s);
+
 template <typename T> hipError_t gemm_minus(int64_t m, int64_t n, int64_t k, const T* A, const T* B, T* C, int64_t ld,
                                             hipStream_t s) {
+  return gemm_minus3<T>(m, n, k, A, ld, B, ld, C, ld, s);
+}
+
+template <typename T> hipError_t gemm_minus3(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B,
+                                             int64_t ldb, T* C, int64_t ldc, hipStream_t s) {
   if (m <= 0 || n <= 0 || k <= 0) return hipSuccess;
   GemmCall c;
   c.kind = KindOf<T>::value;
@@ -202,9 +210,9 @@ template <typename T> hipError_t gemm_minus(int64_t m, int64_t n, int64_t k, con
   c.m = m; c.n = n; c.k = k;
   c.alpha[0] = -1.0; c.alpha[1] = 0.0;
   c.beta[0] = 1.0; c.beta[1] = 0.0;
-  c.A = A; c.lda = ld;
-  c.B = B; c.ldb = ld;
-  c.C = C; c.ldc = ld;
+  c.A = A; c.lda = lda;
+  c.B = B; c.ldb = ldb;
+  c.C = C; c.ldc = ldc;
   return KindOf<T>::value == F64 ? launch_gemm_f64(c, s) : launch_gemm_f32(c, s);
 }
 
@@ -257,16 +265,20 @@ hipError_t laswp(T* A, int64_t ld, int64_t ncols, const int* transp, int k0, int
 // B (bs x ncols) <- L^-1 B with L the unit lower triangle of the bs x bs block at L:
 // 32-row steps of forward substitution, the rows below updated by the GEMM kernel.
 template <typename T>
-hipError_t trsm_unit_lower(const T* L, T* B, int64_t ld, int64_t bs, int64_t ncols, hipStream_t s) {
+hipError_t trsm_unit_lower2(const T* L, int64_t ldl, T* B, int64_t ldb, int64_t bs, int64_t ncols, hipStream_t s) {
   if (ncols <= 0) return hipSuccess;
   constexpr int JB = 32;
   for (int64_t j = 0; j < bs; j += JB) {
     const int jb = (int)std::min<int64_t>(JB, bs - j);
-    hipLaunchKernelGGL((lu_trsm_small<T, JB>), dim3((unsigned)((ncols + 63) / 64)), dim3(64), 0, s, L + j + j * ld, ld,
-                       B + j, ld, jb, (int)ncols);
-    LU_TRY(gemm_minus<T>(bs - j - jb, ncols, jb, L + (j + jb) + j * ld, B + j, B + j + jb, ld, s));
+    hipLaunchKernelGGL((lu_trsm_small<T, JB>), dim3((unsigned)((ncols + 63) / 64)), dim3(64), 0, s, L + j + j * ldl, ldl,
+                       B + j, ldb, jb, (int)ncols);
+    LU_TRY(gemm_minus3<T>(bs - j - jb, ncols, jb, L + (j + jb) + j * ldl, ldl, B + j, ldb, B + j + jb, ldb, s));
   }
   return hipGetLastError();
+}
+template <typename T>
+hipError_t trsm_unit_lower(const T* L, T* B, int64_t ld, int64_t bs, int64_t ncols, hipStream_t s) {
+  return trsm_unit_lower2<T>(L, ld, B, ld, bs, ncols, s);
 }
 
 // blocked_lu (PartialPivLU.h:429-498).  A points at the (row0, row0) corner of the
@@ -312,10 +324,70 @@ hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows
   return hipSuccess;
 }
 
+// Top level of blocked_lu with look-ahead: the panel of step k+1 is factorised on the
+// `panel` stream while the bulk of the trailing update of step k still runs on the
+// `update` stream.  Per step, on the update stream and in this order: the columns of
+// the NEXT panel are brought up to date first (transpositions, triangular solve, GEMM)
+// and an event is recorded; then the transpositions of the columns to the left, and
+// transpositions / solve / GEMM of the remaining trailing columns.  The panel stream
+// waits for that event only.  The arithmetic and its order per element are those of
+// the sequential algorithm; only independent pieces overlap:
+//  * the panel of step k+1 touches columns [k+bs, k+2bs), rows >= k+bs: written by the
+//    "next panel" GEMM before the event, never touched by the remaining GEMM of step k;
+//  * the remaining GEMM of step k reads A21 of panel k (columns [k, k+bs)), which the
+//    transpositions of panel k+1 on the left columns would move: those are queued on
+//    the update stream, behind that GEMM.
+struct LuStreams {
+  hipStream_t panel = nullptr;
+  hipEvent_t ready = nullptr;      // update -> panel: next panel's columns are current
+  hipEvent_t factored = nullptr;   // panel -> update: panel factorised, transpositions known
+};
+
+template <typename T>
+hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* transp, int64_t max_block,
+                             const Workspace<T>& w, const LuStreams& st, hipStream_t upd) {
+  const int64_t size = std::min(rows, cols);
+  if (size <= kMaxBase) return blocked<T>(A, ld, 0, 0, rows, cols, transp, max_block, w, upd);
+  const int64_t block = block_size_rule(size, max_block);
+  hipStream_t pan = st.panel;
+  LU_TRY(hipEventRecord(st.ready, upd));  // everything queued before the call
+  for (int64_t k = 0; k < size; k += block) {
+    const int64_t bs = std::min(size - k, block);
+    const int64_t trows = rows - k - bs, tsize = size - k - bs;
+    LU_TRY(hipStreamWaitEvent(pan, st.ready, 0));
+    LU_TRY(blocked<T>(A, ld, k, k, trows + bs, bs, transp, 16, w, pan));
+    LU_TRY(hipEventRecord(st.factored, pan));
+    LU_TRY(hipStreamWaitEvent(upd, st.factored, 0));
+    const int k0 = (int)k, k1 = (int)(k + bs);
+    T* A11 = A + k + k * ld;
+    T* A21 = A + (k + bs) + k * ld;
+    // columns of the next panel first
+    const int64_t nb = trows ? std::min<int64_t>(tsize, block) : 0;
+    if (nb > 0) {
+      T* A12 = A + k + (k + bs) * ld;
+      LU_TRY(laswp<T>(A + (k + bs) * ld, ld, nb, transp, k0, k1, upd));
+      LU_TRY(trsm_unit_lower<T>(A11, A12, ld, bs, nb, upd));
+      LU_TRY(gemm_minus<T>(trows, nb, bs, A21, A12, A12 + bs, ld, upd));
+    }
+    LU_TRY(hipEventRecord(st.ready, upd));
+    // columns to the left (A_0), then the rest of the trailing matrix (A_2)
+    LU_TRY(laswp<T>(A, ld, k, transp, k0, k1, upd));
+    if (trows && tsize > nb) {
+      T* A12 = A + k + (k + bs + nb) * ld;
+      LU_TRY(laswp<T>(A + (k + bs + nb) * ld, ld, tsize - nb, transp, k0, k1, upd));
+      LU_TRY(trsm_unit_lower<T>(A11, A12, ld, bs, tsize - nb, upd));
+      LU_TRY(gemm_minus<T>(trows, tsize - nb, bs, A21, A12, A12 + bs, ld, upd));
+    }
+  }
+  // the panel stream has nothing queued after the last `factored` event
+  return hipSuccess;
+}
+
 struct LuScratch {
   std::mutex mu;
   void* buf = nullptr;
   size_t cap = 0;
+  LuStreams streams;
 };
 LuScratch& scratch() {
   static LuScratch s;
@@ -323,8 +395,8 @@ LuScratch& scratch() {
 }
 
 template <typename T>
-hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp, int* first_zero_pivot,
-                          int* nb_transpositions, hipStream_t s) {
+hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp, int64_t max_block,
+                          int* first_zero_pivot, int* nb_transpositions, hipStream_t s) {
   LuScratch& sc = scratch();
   std::lock_guard<std::mutex> lock(sc.mu);
   const size_t nparts = (size_t)((m + kRowsPerBlock - 1) / kRowsPerBlock) + 1;
@@ -344,7 +416,18 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   w.partials = reinterpret_cast<Candidate<T>*>(p + 64 + ((sizeof(Side<T>) + 63) / 64) * 64);
   LU_TRY(hipMemsetAsync(w.first_zero, 0xFF, sizeof(int), s));  // -1
   LU_TRY(hipMemsetAsync(w.nswaps, 0, sizeof(int), s));
-  LU_TRY(blocked<T>(A, ld, 0, 0, m, n, d_transp, 256, w, s));
+  if (!sc.streams.panel) {
+    int lo = 0, hi = 0;
+    LU_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    LU_TRY(hipStreamCreateWithPriority(&sc.streams.panel, hipStreamNonBlocking, hi));
+    LU_TRY(hipEventCreateWithFlags(&sc.streams.ready, hipEventDisableTiming));
+    LU_TRY(hipEventCreateWithFlags(&sc.streams.factored, hipEventDisableTiming));
+  }
+  if (max_block > 16) {
+    LU_TRY(blocked_lookahead<T>(A, ld, m, n, d_transp, max_block, w, sc.streams, s));
+  } else {  // a panel: nothing to overlap with
+    LU_TRY(blocked<T>(A, ld, 0, 0, m, n, d_transp, max_block, w, s));
+  }
   int out[2] = {-1, 0};
   LU_TRY(hipMemcpyAsync(out, w.first_zero, sizeof out, hipMemcpyDeviceToHost, s));
   LU_TRY(hipStreamSynchronize(s));
@@ -355,12 +438,31 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
 
 }  // namespace
 
-hipError_t getrf_device(int kind, int64_t m, int64_t n, void* A, int64_t ld, int* d_transp, int* first_zero_pivot,
-                        int* nb_transpositions, hipStream_t s) {
+hipError_t getrf_device(int kind, int64_t m, int64_t n, void* A, int64_t ld, int* d_transp, int64_t max_block,
+                        int* first_zero_pivot, int* nb_transpositions, hipStream_t s) {
+  if (max_block < 8) max_block = 8;
   if (kind == F64)
-    return getrf_device_t<double>(m, n, static_cast<double*>(A), ld, d_transp, first_zero_pivot, nb_transpositions, s);
+    return getrf_device_t<double>(m, n, static_cast<double*>(A), ld, d_transp, max_block, first_zero_pivot,
+                                  nb_transpositions, s);
   if (kind == F32)
-    return getrf_device_t<float>(m, n, static_cast<float*>(A), ld, d_transp, first_zero_pivot, nb_transpositions, s);
+    return getrf_device_t<float>(m, n, static_cast<float*>(A), ld, d_transp, max_block, first_zero_pivot,
+                                 nb_transpositions, s);
+  return hipErrorInvalidValue;
+}
+
+hipError_t laswp_device(int kind, void* A, int64_t ld, int64_t ncols, const int* d_transp, int k0, int k1,
+                        hipStream_t s) {
+  if (kind == F64) return laswp<double>(static_cast<double*>(A), ld, ncols, d_transp, k0, k1, s);
+  if (kind == F32) return laswp<float>(static_cast<float*>(A), ld, ncols, d_transp, k0, k1, s);
+  return hipErrorInvalidValue;
+}
+
+hipError_t trsm_llnu_device(int kind, int64_t bs, int64_t ncols, const void* L, int64_t ldl, void* B, int64_t ldb,
+                            hipStream_t s) {
+  if (kind == F64)
+    return trsm_unit_lower2<double>(static_cast<const double*>(L), ldl, static_cast<double*>(B), ldb, bs, ncols, s);
+  if (kind == F32)
+    return trsm_unit_lower2<float>(static_cast<const float*>(L), ldl, static_cast<float*>(B), ldb, bs, ncols, s);
   return hipErrorInvalidValue;
 }
 

@@ -9,7 +9,17 @@ namespace eigamd {
 // or F64.  d_transp (device, min(m,n) ints) receives the 0-based row transpositions
 // as global row indices; *first_zero_pivot the index of the first exactly-zero pivot
 // or -1; *nb_transpositions the number of actual row swaps.  Synchronises `s`.
-hipError_t getrf_device(int kind, int64_t m, int64_t n, void* A, int64_t ld, int* d_transp, int* first_zero_pivot,
-                        int* nb_transpositions, hipStream_t s);
+// max_block is the maxBlockSize of blocked_lu (256 at top level, 16 for a panel).
+hipError_t getrf_device(int kind, int64_t m, int64_t n, void* A, int64_t ld, int* d_transp, int64_t max_block,
+                        int* first_zero_pivot, int* nb_transpositions, hipStream_t s);
+
+// Row transpositions i <-> d_transp[i], i in [k0, k1), on ncols columns starting at A
+// (row indices are rows of A).
+hipError_t laswp_device(int kind, void* A, int64_t ld, int64_t ncols, const int* d_transp, int k0, int k1,
+                        hipStream_t s);
+
+// B (bs x ncols) <- L^-1 B, L the unit lower triangle of a bs x bs block.
+hipError_t trsm_llnu_device(int kind, int64_t bs, int64_t ncols, const void* L, int64_t ldl, void* B, int64_t ldb,
+                            hipStream_t s);
 
 }  // namespace eigamd

@@ -40,15 +40,34 @@ def getrf(a):
     return ipiv[:min(m, n)], info.value
 
 
-def getrf_dev(a, stream=None):
+def getrf_dev(a, stream=None, max_block_size=256, transp=None):
     """In-place LU of a DeviceMatrix.  Returns (transpositions as an int32 cuda tensor,
-    nb_transpositions, first_zero_pivot)."""
+    nb_transpositions, first_zero_pivot).  max_block_size = 16 factorises `a` as one
+    panel of the blocked algorithm."""
     import torch
     from .device import _stream_ptr
     size = min(a.rows, a.cols)
-    transp = torch.zeros(max(size, 1), dtype=torch.int32, device=a.storage.device)
+    if transp is None:
+        transp = torch.zeros(max(size, 1), dtype=torch.int32, device=a.storage.device)
     nb, fz = ctypes.c_int(0), ctypes.c_int(-1)
     rc = lib.eigamd_getrf_dev(a.kind, a.rows, a.cols, ctypes.c_void_p(a.ptr), a.ld, ctypes.c_void_p(transp.data_ptr()),
-                              ctypes.byref(fz), ctypes.byref(nb), _stream_ptr(stream))
+                              max_block_size, ctypes.byref(fz), ctypes.byref(nb), _stream_ptr(stream))
     _lib.check(rc, "eigamd_getrf_dev")
     return transp[:size], nb.value, fz.value
+
+
+def laswp_dev(a, transp, k0, k1, stream=None):
+    """Exchange rows i and transp[i] of the DeviceMatrix `a`, i = k0 .. k1-1 in order
+    (transp: int32 device tensor of row indices of `a`)."""
+    from .device import _stream_ptr
+    rc = lib.eigamd_laswp_dev(a.kind, ctypes.c_void_p(a.ptr), a.ld, a.cols, ctypes.c_void_p(transp.data_ptr()), k0, k1,
+                              _stream_ptr(stream))
+    _lib.check(rc, "eigamd_laswp_dev")
+
+
+def trsm_llnu_dev(l, b, stream=None):
+    """b <- l^-1 b with `l` the unit lower triangle of a square DeviceMatrix block."""
+    from .device import _stream_ptr
+    rc = lib.eigamd_trsm_llnu_dev(b.kind, b.rows, b.cols, ctypes.c_void_p(l.ptr), l.ld, ctypes.c_void_p(b.ptr), b.ld,
+                                  _stream_ptr(stream))
+    _lib.check(rc, "eigamd_trsm_llnu_dev")

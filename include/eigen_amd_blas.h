@@ -99,13 +99,26 @@ int eigamd_fill_uniform_cyclic_dev(int dtype, void* d_x, int64_t rows, int64_t c
  * ipiv, info = -i for a bad argument i (through xerbla_), else first zero pivot + 1.
  *
  * eigamd_getrf_dev factorises a matrix already in HBM; d_transp is device memory
- * (min(m,n) ints).  It synchronises `stream` before returning the two counters. */
+ * (min(m,n) ints); max_block_size is blocked_lu's maxBlockSize argument (256 for a
+ * whole matrix, 16 for one panel, PartialPivLU.h:429,472).  It synchronises `stream`
+ * before returning the two counters. */
 int eigamd_blocked_lu_host(int dtype, int64_t rows, int64_t cols, void* lu, int64_t lu_stride,
                            int* row_transpositions, int* nb_transpositions, int* first_zero_pivot);
 int dgetrf_(const int* m, const int* n, double* a, const int* lda, int* ipiv, int* info);
 int sgetrf_(const int* m, const int* n, float* a, const int* lda, int* ipiv, int* info);
 int eigamd_getrf_dev(int dtype, int64_t m, int64_t n, void* d_a, int64_t lda, int* d_transp,
-                     int* first_zero_pivot, int* nb_transpositions, void* stream);
+                     int64_t max_block_size, int* first_zero_pivot, int* nb_transpositions, void* stream);
+
+/* The two other steps of one blocked_lu iteration, on device memory, for drivers that
+ * own the loop themselves (the multi-GPU LU): the row transpositions of
+ * PartialPivLU.h:479-489 -- rows i and d_transp[i] of `ncols` columns starting at d_a
+ * are exchanged for i = k0 .. k1-1, in order -- and A12 = A11^-1 A12 with A11 unit
+ * lower triangular (PartialPivLU.h:492), i.e. ?trsm_("L","L","N","U", m, n, 1, ...) of
+ * blas/level3_impl.h:78-178 restricted to that one form. */
+int eigamd_laswp_dev(int dtype, void* d_a, int64_t lda, int64_t ncols, const int* d_transp, int k0, int k1,
+                     void* stream);
+int eigamd_trsm_llnu_dev(int dtype, int64_t m, int64_t n, const void* d_l, int64_t ldl, void* d_b, int64_t ldb,
+                         void* stream);
 
 /* ---- misc --------------------------------------------------------------------- */
 const char* eigamd_last_error(void);  /* text of the last failure on this thread */
