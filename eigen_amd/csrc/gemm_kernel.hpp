@@ -67,6 +67,13 @@ struct GemmParams {
 #define EIGAMD_C32_SHAPE 2, 2, 2, 2, 16, 2, 1
 #endif
 
+// Profiling builds can switch stages of the main loop off (results are then wrong; the
+// timing shows what the remaining stages cost): 1 = no global loads, 2 = no LDS
+// stores, 4 = no barrier.  Never set in the shipped library.
+#ifndef EIGAMD_ABLATE
+#define EIGAMD_ABLATE 0
+#endif
+
 template <int WM_, int WN_, int MT_, int NT_, int BK_, int PER_CU_, int PREFETCH_> struct Shape {
   static constexpr int WM = WM_, WN = WN_, MT = MT_, NT = NT_, BK = BK_, PER_CU = PER_CU_;
   static constexpr bool PREFETCH = PREFETCH_ != 0;
@@ -340,7 +347,7 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
     const Elem* sa = smem + (t & 1) * (LDS_A + LDS_B) + fa0;
     const Elem* sb = smem + (t & 1) * (LDS_A + LDS_B) + LDS_A + fb0;
     const bool more = t + 1 < ntiles;
-    if (more) gload(t + 1);
+    if (more && !(EIGAMD_ABLATE & 1)) gload(t + 1);
 
     // With PREFETCH the fragments of k-step ks+1 are read while the MFMAs of k-step ks
     // issue; without it each k-step reads its own fragments and the compiler interleaves.
@@ -393,12 +400,12 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
       }
     }
 
-    if (more) {
+    if (more && !(EIGAMD_ABLATE & 2)) {
       Elem* da = smem + ((t + 1) & 1) * (LDS_A + LDS_B);
       ioa.store(ra, da);
       iob.store(rb, da + LDS_A);
     }
-    __syncthreads();
+    if (!(EIGAMD_ABLATE & 4)) __syncthreads();
   }
 
   // Epilogue: C = alpha * acc + beta * C.  beta == 0 never reads C
