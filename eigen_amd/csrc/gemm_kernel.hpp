@@ -25,6 +25,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace eigamd {
 
@@ -53,18 +54,21 @@ struct GemmParams {
 // other shapes (tools/build_variant.sh); the defaults are the shipped configuration.
 // Shape = WM, WN, MT, NT, BK, workgroups per CU the register budget is sized for,
 // and whether the fragments of k-step ks+1 are read explicitly ahead of the MFMAs of
-// k-step ks (1) or the order is left to the compiler's scheduler (0).
+// k-step ks (1) or the order is left to the compiler's scheduler (0).  Two optional values
+// follow: the operand pipeline (1 = interleaved, see the main loop of gemm_kernel) and,
+// for that pipeline, the divisor d: the LDS writes of the next tile are spread over the
+// first KSTEPS / d k-steps and the global loads over as many k-steps after them.
 #ifndef EIGAMD_F64_SHAPE
-#define EIGAMD_F64_SHAPE 2, 2, 4, 4, 16, 2, 0
+#define EIGAMD_F64_SHAPE 2, 2, 4, 4, 16, 2, 1, 1, 4
 #endif
 #ifndef EIGAMD_F32_SHAPE
-#define EIGAMD_F32_SHAPE 2, 4, 4, 2, 32, 1, 1
+#define EIGAMD_F32_SHAPE 2, 4, 4, 2, 32, 1, 1, 1, 2
 #endif
 #ifndef EIGAMD_C64_SHAPE
 #define EIGAMD_C64_SHAPE 2, 2, 4, 2, 8, 2, 1
 #endif
 #ifndef EIGAMD_C32_SHAPE
-#define EIGAMD_C32_SHAPE 2, 2, 2, 2, 16, 2, 1
+#define EIGAMD_C32_SHAPE 2, 2, 2, 2, 16, 2, 1, 1, 4
 #endif
 
 // Profiling builds can switch stages of the main loop off (results are then wrong; the
@@ -74,9 +78,12 @@ struct GemmParams {
 #define EIGAMD_ABLATE 0
 #endif
 
-template <int WM_, int WN_, int MT_, int NT_, int BK_, int PER_CU_, int PREFETCH_> struct Shape {
+template <int WM_, int WN_, int MT_, int NT_, int BK_, int PER_CU_, int PREFETCH_, int PIPE_ = 0, int SPREAD_DIV_ = 4>
+struct Shape {
   static constexpr int WM = WM_, WN = WN_, MT = MT_, NT = NT_, BK = BK_, PER_CU = PER_CU_;
   static constexpr bool PREFETCH = PREFETCH_ != 0;
+  static constexpr bool PIPE = PIPE_ != 0;
+  static constexpr int SPREAD_DIV = SPREAD_DIV_;
 };
 
 template <int KIND> struct Traits;
@@ -192,43 +199,48 @@ template <int KIND, bool KC, int BX> struct TileIO {
     return (int64_t)row0 * ld + col0;
   }
   // Unguarded: whole chunks, 16-byte aligned.
+  __device__ __forceinline__ void load_one(uint4& r, int i, const Elem* p, int64_t ld) const {
+    r = *reinterpret_cast<const uint4*>(p + (int64_t)(i * ROWSTEP) * ld);
+  }
   __device__ __forceinline__ void load(uint4 (&r)[NCHUNK], const Elem* p, int64_t ld) const {
 #pragma unroll
-    for (int i = 0; i < NCHUNK; ++i)
-      r[i] = *reinterpret_cast<const uint4*>(p + (int64_t)(i * ROWSTEP) * ld);
+    for (int i = 0; i < NCHUNK; ++i) load_one(r[i], i, p, ld);
   }
   // Guarded: element-wise, zero outside [0,xrem) x [0,krem).  Needs only
   // element alignment.
+  __device__ __forceinline__ void load_guard_one(uint4& r, int i, const Elem* p, int64_t ld,
+                                                 int xrem, int krem) const {
+    union { uint4 v; Elem e[EPC]; } u;
+    const int row = row0 + i * ROWSTEP;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const int col = col0 + e;
+      const int x = KC ? row : col;
+      const int k = KC ? col : row;
+      Elem z = {};
+      u.e[e] = (x < xrem && k < krem) ? p[(int64_t)(i * ROWSTEP) * ld + e] : z;
+    }
+    r = u.v;
+  }
   __device__ __forceinline__ void load_guard(uint4 (&r)[NCHUNK], const Elem* p, int64_t ld,
                                              int xrem, int krem) const {
 #pragma unroll
-    for (int i = 0; i < NCHUNK; ++i) {
+    for (int i = 0; i < NCHUNK; ++i) load_guard_one(r[i], i, p, ld, xrem, krem);
+  }
+  __device__ __forceinline__ void store_one(const uint4& r, int i, Elem* lds) const {
+    Elem* dst = lds + (row0 + i * ROWSTEP) * PITCH + col0;
+    if constexpr (!KC || T::kVecWriteK) {
+      *reinterpret_cast<uint4*>(dst) = r;
+    } else {
       union { uint4 v; Elem e[EPC]; } u;
-      const int row = row0 + i * ROWSTEP;
+      u.v = r;
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) {
-        const int col = col0 + e;
-        const int x = KC ? row : col;
-        const int k = KC ? col : row;
-        Elem z = {};
-        u.e[e] = (x < xrem && k < krem) ? p[(int64_t)(i * ROWSTEP) * ld + e] : z;
-      }
-      r[i] = u.v;
+      for (int e = 0; e < EPC; ++e) dst[e] = u.e[e];
     }
   }
   __device__ __forceinline__ void store(const uint4 (&r)[NCHUNK], Elem* lds) const {
 #pragma unroll
-    for (int i = 0; i < NCHUNK; ++i) {
-      Elem* dst = lds + (row0 + i * ROWSTEP) * PITCH + col0;
-      if constexpr (!KC || T::kVecWriteK) {
-        *reinterpret_cast<uint4*>(dst) = r[i];
-      } else {
-        union { uint4 v; Elem e[EPC]; } u;
-        u.v = r[i];
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) dst[e] = u.e[e];
-      }
-    }
+    for (int i = 0; i < NCHUNK; ++i) store_one(r[i], i, lds);
   }
   // LDS element index of fragment element (x, k).
   __device__ static __forceinline__ int frag_index(int x, int k) {
@@ -318,36 +330,89 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
   }
 
   const int ntiles = (p.K + BK - 1) / BK;
-  auto gload = [&](int t) {
-    const int krem = p.K - t * BK;
-    if (GUARD || krem < BK) {
-      ioa.load_guard(ra, pa, p.lda, mrem, krem);
-      iob.load_guard(rb, pb, p.ldb, nrem, krem);
+  constexpr int KSTEPS = BK / KS;
+  constexpr int NA = IOA::NCHUNK, NB = IOB::NCHUNK, NCH = NA + NB;
+  constexpr bool PIPE = T::S::PIPE;
+  // Software pipeline of the operand tiles.  The stage that tile t is multiplied from was
+  // written one tile earlier; what differs is where the copy of the following tiles sits:
+  //   PIPE = 0: tile t+1 is loaded from global memory before the MFMAs of tile t and
+  //             written to LDS after them;
+  //   PIPE = 1: the registers already hold tile t+1 (loaded during tile t-1); its LDS
+  //             writes and then the global loads of tile t+2 are spread over the first
+  //             k-steps of tile t, between the MFMAs, so no wavefront has a store-only
+  //             phase in front of the barrier.
+  // Work is placed in "slots": slot ks is issued in front of k-step ks, slot KSTEPS after
+  // the last one.
+  constexpr int LEAD = PIPE ? 2 : 1;
+  constexpr int SPREAD = KSTEPS / T::S::SPREAD_DIV > 0 ? KSTEPS / T::S::SPREAD_DIV : 1;
+  auto store_slot = [](int c) constexpr { return PIPE ? c * SPREAD / NCH : KSTEPS; };
+  auto load_slot = [](int c) constexpr {
+    const int s = SPREAD + c * SPREAD / NCH;
+    return PIPE ? (s < KSTEPS ? s : KSTEPS - 1) : 0;
+  };
+
+  auto load_chunk = [&](int c, bool guard, int krem) {
+    if (c < NA) {
+      if (guard) ioa.load_guard_one(ra[c < NA ? c : 0], c, pa, p.lda, mrem, krem);
+      else ioa.load_one(ra[c < NA ? c : 0], c, pa, p.lda);
     } else {
-      ioa.load(ra, pa, p.lda);
-      iob.load(rb, pb, p.ldb);
+      const int d = c < NA ? 0 : c - NA;
+      if (guard) iob.load_guard_one(rb[d], d, pb, p.ldb, nrem, krem);
+      else iob.load_one(rb[d], d, pb, p.ldb);
     }
+  };
+  auto store_chunk = [&](int c, Elem* stage) {
+    if (c < NA) ioa.store_one(ra[c < NA ? c : 0], c, stage);
+    else iob.store_one(rb[c < NA ? 0 : c - NA], c < NA ? 0 : c - NA, stage + LDS_A);
+  };
+  // Whole tile `t` into the staging registers (prologue only).
+  auto load_tile = [&](int t) {
+    const int krem = p.K - t * BK;
+    const bool guard = GUARD || krem < BK;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) load_chunk(c, guard, krem);
     pa += stepa;
     pb += stepb;
   };
 
   if (ntiles > 0) {
-    gload(0);
-    ioa.store(ra, smem);
-    iob.store(rb, smem + LDS_A);
+    load_tile(0);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) store_chunk(c, smem);
+    if (PIPE && ntiles > 1) load_tile(1);
   }
   __syncthreads();
 
   // Per-lane fragment origins inside a stage.
   const int fa0 = IOA::frag_index(wm0 + xi, kk);
   const int fb0 = IOB::frag_index(wn0 + xi, kk);
-  constexpr int KSTEPS = BK / KS;
 
-  for (int t = 0; t < ntiles; ++t) {
+  // One tile of the reduction.  STEADY: tiles t+1 and t+LEAD exist and are whole, nothing
+  // is tested; otherwise both are tested and partial tiles take the guarded loads.
+  auto tile = [&](int t, auto steady_c) {
+    constexpr bool STEADY = decltype(steady_c)::value;
     const Elem* sa = smem + (t & 1) * (LDS_A + LDS_B) + fa0;
     const Elem* sb = smem + (t & 1) * (LDS_A + LDS_B) + LDS_A + fb0;
-    const bool more = t + 1 < ntiles;
-    if (more && !(EIGAMD_ABLATE & 1)) gload(t + 1);
+    Elem* next_stage = smem + ((t + 1) & 1) * (LDS_A + LDS_B);
+    const int krem = p.K - (t + LEAD) * BK;
+    const bool do_store = (STEADY || t + 1 < ntiles) && !(EIGAMD_ABLATE & 2);
+    const bool do_load = (STEADY || t + LEAD < ntiles) && !(EIGAMD_ABLATE & 1);
+    const bool guard = !STEADY && (GUARD || krem < BK);
+    // In the interleaved pipeline the position of the copies among the MFMAs is the
+    // point, so the instruction scheduler may not move anything across a used slot.
+    auto slot = [&](int s) {
+      bool used = false;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) used = used || store_slot(c) == s || load_slot(c) == s;
+      if (PIPE && used) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+        if (store_slot(c) == s && do_store) store_chunk(c, next_stage);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+        if (load_slot(c) == s && do_load) load_chunk(c, guard, krem);
+      if (PIPE && used) __builtin_amdgcn_sched_barrier(0);
+    };
 
     // With PREFETCH the fragments of k-step ks+1 are read while the MFMAs of k-step ks
     // issue; without it each k-step reads its own fragments and the compiler interleaves.
@@ -360,6 +425,7 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
     }
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
+      slot(ks);
       const int cur = T::S::PREFETCH ? (ks & 1) : 0, nxt = cur ^ 1;
       if constexpr (T::S::PREFETCH) {
         if (ks + 1 < KSTEPS) {
@@ -399,14 +465,20 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
         }
       }
     }
-
-    if (more && !(EIGAMD_ABLATE & 2)) {
-      Elem* da = smem + ((t + 1) & 1) * (LDS_A + LDS_B);
-      ioa.store(ra, da);
-      iob.store(rb, da + LDS_A);
+    slot(KSTEPS);
+    if (do_load) {
+      pa += stepa;
+      pb += stepb;
     }
     if (!(EIGAMD_ABLATE & 4)) __syncthreads();
+  };
+
+  int t = 0;
+  if constexpr (!GUARD) {
+    const int nfull = p.K / BK;
+    for (; t + LEAD < nfull; ++t) tile(t, std::true_type{});
   }
+  for (; t < ntiles; ++t) tile(t, std::false_type{});
 
   // Epilogue: C = alpha * acc + beta * C.  beta == 0 never reads C
   // (blas/level3_impl.h:64: NaN/Inf in C must not propagate).  Per column group j the

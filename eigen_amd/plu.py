@@ -21,7 +21,7 @@ import torch.distributed as dist
 
 from . import _lib
 from .device import DeviceMatrix, _TORCH_OF_KIND
-from .summa import global_indices, numroc
+from .summa import device_broadcast, global_indices, numroc
 
 
 def lu_block_size(size, max_block=256):
@@ -83,9 +83,11 @@ class DeviceOps:
         gemm_dev("N", "N", -1.0, a21, a12, 1.0, a22)
 
 
-def pgetrf(A, ops=DeviceOps):
+def pgetrf(A, ops=DeviceOps, broadcast=None):
     """In-place P*A = L*U of a ColCyclicMatrix.  Returns (transpositions: int32 tensor of
     n global row indices on A's device, nb_transpositions, first_zero_pivot)."""
+    if broadcast is None:
+        broadcast = device_broadcast
     n, nb, P, r = A.n, A.nb, A.world, A.rank
     if nb != lu_block_size(n):
         raise ValueError(f"column block {nb} must equal the LU block size {lu_block_size(n)} for n = {n}")
@@ -111,8 +113,7 @@ def pgetrf(A, ops=DeviceOps):
             meta[nb] = fz
             meta[nb + 1] = ns
         if P > 1:
-            works = [dist.broadcast(pbuf[:rows_p * bs], src=owner, async_op=True),
-                     dist.broadcast(meta, src=owner, async_op=True)]
+            works = [broadcast(pbuf[:rows_p * bs], owner), broadcast(meta, owner)]
             for w in works:
                 w.wait()
         fz, ns = int(meta[nb].item()), int(meta[nb + 1].item())

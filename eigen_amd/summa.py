@@ -122,9 +122,32 @@ def _default_local_gemm(alpha, a, b, beta, c):
     gemm_dev("N", "N", alpha, a, b, beta, c)
 
 
-def pgemm(alpha, A, B, beta, C, local_gemm=None):
+def device_broadcast(t, src, group=None):
+    """Panel exchange on the communication backend itself (RCCL with backend "nccl"):
+    asynchronous, returns the work handle."""
+    return dist.broadcast(t, src=src, group=group, async_op=True)
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+def host_staged_broadcast(t, src, group=None):
+    """Panel exchange through a host copy: for backends without a device transport (gloo
+    ranks that share one GPU in the tests).  Synchronous."""
+    h = t.cpu() if dist.get_rank() == src else torch.empty(t.shape, dtype=t.dtype)
+    dist.broadcast(h, src=src, group=group)
+    if dist.get_rank() != src:
+        t.copy_(h)
+    return _Done()
+
+
+def pgemm(alpha, A, B, beta, C, local_gemm=None, broadcast=None):
     """C <- alpha*A*B + beta*C (no transposes).  A is M x K with blocks (nb_m, kb), B is
     K x N with blocks (kb, nb_n), C is M x N with blocks (nb_m, nb_n), all on one grid."""
+    if broadcast is None:
+        broadcast = device_broadcast
     g = C.grid
     if not (A.rows == C.rows and B.cols == C.cols and A.cols == B.rows):
         raise ValueError("shape mismatch")
@@ -156,8 +179,7 @@ def pgemm(alpha, A, B, beta, C, local_gemm=None):
                 flat = abuf[p % 2][:A.mloc * w]
                 a_view = DeviceMatrix(A.mloc, w, A.kind, ld=max(A.mloc, 1), storage=abuf[p % 2])
             if A.mloc * w > 0:
-                works.append(dist.broadcast(_flat_real(flat), src=g.row_ranks[a_owner], group=g.row_group,
-                                            async_op=True))
+                works.append(broadcast(_flat_real(flat), g.row_ranks[a_owner], g.row_group))
         # --- B(panel p, :): owned by grid row p % nprow, local rows (p // nprow)*kb ...
         b_owner, b_off = p % g.nprow, (p // g.nprow) * kb
         if g.nprow == 1:
@@ -169,8 +191,7 @@ def pgemm(alpha, A, B, beta, C, local_gemm=None):
                 # pack the strided row block into the contiguous send buffer
                 b_view.as_strided().copy_(B.local.block(b_off, 0, w, B.nloc).as_strided())
             if w * B.nloc > 0:
-                works.append(dist.broadcast(_flat_real(flat), src=g.col_ranks[b_owner], group=g.col_group,
-                                            async_op=True))
+                works.append(broadcast(_flat_real(flat), g.col_ranks[b_owner], g.col_group))
         return a_view, b_view, works
 
     if npanels == 0:

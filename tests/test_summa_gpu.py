@@ -1,8 +1,10 @@
-"""The multi-GPU GEMM driver with the real HIP local product and the real
+"""The multi-GPU GEMM and LU drivers with the real HIP local steps and the real
 block-cyclic device generator, on ONE GPU: 2 and 4 ranks share cuda:0 and exchange
 panels over gloo (RCCL refuses several ranks on one device, so the nccl transport
-itself is only exercised on a multi-GPU node).  Each rank checks its local part of
-C against the product of the globally defined operands."""
+itself is only exercised on a multi-GPU node).  Panels travel through a host copy
+(host_staged_broadcast); EIGAMD_TEST_DEVICE_BCAST=1 hands the device tensors to the
+backend instead, which gloo's device path does not do reliably when the ranks share
+a card.  Each rank checks its local part against the globally defined result."""
 import os
 import socket
 
@@ -21,6 +23,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _bcast():
+    from eigen_amd.summa import device_broadcast, host_staged_broadcast
+    return device_broadcast if os.environ.get("EIGAMD_TEST_DEVICE_BCAST") else host_staged_broadcast
+
+
 def _worker(rank, world, port, kind, n, nb):
     import faulthandler
     import sys
@@ -33,6 +40,7 @@ def _worker(rank, world, port, kind, n, nb):
     from eigen_amd.summa import DistMatrix, Grid, pgemm
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
+    torch.cuda.set_stream(torch.cuda.Stream())   # not the legacy default stream
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         grid = Grid()
@@ -44,7 +52,7 @@ def _worker(rank, world, port, kind, n, nb):
         # the distributed generator reproduces the single-device matrix
         assert np.array_equal(A.local.to_numpy(), a[np.ix_(A.global_rows(), A.global_cols())])
         for step in range(2):   # two accumulating steps, as bench.py runs them
-            pgemm(1.0, A, B, 1.0, C)
+            pgemm(1.0, A, B, 1.0, C, broadcast=_bcast())
         torch.cuda.synchronize()
         want = c0.astype(np.complex128) + 2 * (a.astype(np.complex128) @ b.astype(np.complex128))
         got = C.local.to_numpy()
@@ -73,21 +81,49 @@ def _lu_worker(rank, world, port, n):
     import eigen_amd
     from eigen_amd.device import DeviceMatrix
     from eigen_amd import lu as ealu
-    from eigen_amd.plu import ColCyclicMatrix, lu_block_size, pgetrf
+    from eigen_amd.plu import ColCyclicMatrix, DeviceOps, lu_block_size, pgetrf
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
+    torch.cuda.set_stream(torch.cuda.Stream())   # not the legacy default stream
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         A = ColCyclicMatrix(n, lu_block_size(n), eigen_amd.F64).fill_uniform(77)
         full = rng_np.matrix(np.float64, 77, n, n)
         assert np.array_equal(A.local.to_numpy(), full[:, A.global_cols()])
-        transp, nswaps, fz = pgetrf(A)
+        ops = DeviceOps
+        if os.environ.get("EIGAMD_TEST_VERBOSE"):
+            import time
+            t0 = time.time()
+
+            class ops(DeviceOps):   # progress of every local step, to locate a stuck rank
+                @staticmethod
+                def panel_lu(panel, tr):
+                    print(f"[rank {rank}] +{time.time() - t0:.2f}s panel {panel.rows}x{panel.cols}", flush=True)
+                    return DeviceOps.panel_lu(panel, tr)
+
+                @staticmethod
+                def gemm_minus(a21, a12, a22):
+                    torch.cuda.synchronize()
+                    print(f"[rank {rank}] +{time.time() - t0:.2f}s update {a22.rows}x{a22.cols}", flush=True)
+                    DeviceOps.gemm_minus(a21, a12, a22)
+        transp, nswaps, fz = pgetrf(A, ops, _bcast())
         torch.cuda.synchronize()
-        # single-device factorisation of the same matrix: identical pivots, same factors
-        S = DeviceMatrix(n, n, eigen_amd.F64).fill_uniform(77)
-        t1, nb1, fz1 = ealu.getrf_dev(S)
-        assert torch.equal(transp.cpu(), t1.cpu()) and nswaps == nb1 and fz == fz1 == -1
-        ref = S.to_numpy()[:, A.global_cols()]
+        # single-device factorisation of the same matrix, on rank 0 only (ranks that share
+        # a GPU and each queue thousands of small kernels make the driver time-slice the
+        # card between processes, which is slow): identical pivots, same factors
+        if rank == 0:
+            S = DeviceMatrix(n, n, eigen_amd.F64).fill_uniform(77)
+            t1, nb1, fz1 = ealu.getrf_dev(S)
+            ref_full = torch.from_numpy(S.to_numpy().copy())
+            ref_meta = torch.cat([t1.cpu().to(torch.int64), torch.tensor([nb1, fz1])])
+        else:
+            ref_full = torch.empty((n, n), dtype=torch.float64)
+            ref_meta = torch.empty(n + 2, dtype=torch.int64)
+        dist.broadcast(ref_full, src=0)
+        dist.broadcast(ref_meta, src=0)
+        assert torch.equal(transp.cpu().to(torch.int64), ref_meta[:n])
+        assert nswaps == int(ref_meta[n]) and fz == int(ref_meta[n + 1]) == -1
+        ref = ref_full.numpy()[:, A.global_cols()]
         got = A.local.to_numpy()
         assert np.abs(got - ref).max() <= 64 * np.finfo(np.float64).eps * n * np.abs(ref).max(), rank
     finally:

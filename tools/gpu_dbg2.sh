@@ -1,0 +1,8 @@
+#!/bin/bash
+# The multi-rank GPU test file, repeated; stops at the first failing run.
+set -o pipefail
+mkdir -p gpurun_out
+for r in $(seq ${1:-6}); do
+  echo "=== run $r"
+  timeout -k 10 500 python -u -m pytest tests/test_summa_gpu.py -x -q -s --durations=0 --timeout 200 --timeout-method thread 2>&1 | grep --line-buffered -v "Gloo\|amdgpu.ids\|socket.cpp" | tee -a gpurun_out/dbg2.log | grep --line-buffered "passed\|failed\|Timeout\|repo/\|s call\|rank" || exit 1
+done
