@@ -7,9 +7,13 @@
 // blocks of 16 and an unblocked base case, :472-473), the same pivot choice (first
 // row of largest |a|, :375-377), zero-pivot bookkeeping (:391-396) and the same
 // order of row transpositions on the left (A_0) and right (A_2) parts (:479-489).
-// Everything stays in HBM: pivot search, swaps, scaling and rank-1 updates of the
-// base case are small multi-block kernels chained on one stream (a kernel boundary
-// is the grid-wide synchronisation), the pivot indices never visit the host.
+// Everything stays in HBM and the pivot indices never visit the host.  The unblocked
+// base case (a panel of at most 16 columns) is ONE kernel: every thread keeps one row
+// of the panel in registers, the workgroups agree on each pivot through a small
+// exchange area and a grid-wide barrier per column (lu_base_fused).  Panels too tall
+// for all their workgroups to be resident at once fall back to a chain of small
+// kernels per column (lu_colmax / lu_pivot / lu_update), where the kernel boundary is
+// the grid-wide synchronisation.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -146,6 +150,239 @@ __global__ void lu_update(T* __restrict__ P, int64_t ld, int rows, int jbw, int 
   }
 }
 
+// ---- the base case in one kernel ---------------------------------------------------
+//
+// The workgroups of the fused base case agree on each pivot through an exchange area in
+// global memory that is read and written with agent-scope accesses only (they bypass the
+// per-XCD L2, which is not coherent across XCDs).  There is no counter and no atomic
+// read-modify-write: every published word carries the generation it belongs to, and a
+// workgroup simply polls until all words of the current generation are there.
+//
+// Generation G counts pivot columns across launches (the host passes the first G of a
+// launch), buffer G & 1 is used for column G.  Per workgroup and buffer:
+//   w0   = bits of the candidate |a|, bit 63 = (G >> 1) & 1     (|a| >= 0: the bit is free)
+//   w1   = candidate row (low half) | G (high half)
+//   data = the whole panel row of the candidate, written before w0 / w1
+// plus, per buffer, the panel row jj (what the pivot row is swapped with) and its tag G.
+template <typename T> struct BaseSlot {
+  unsigned long long w0;
+  unsigned long long w1;
+  T data[kMaxBase];
+};
+template <typename T> struct BaseTop {
+  T data[kMaxBase];
+  unsigned long long tag;
+  unsigned long long pad;
+};
+constexpr int kMaxFusedParts = 1024;   // workgroups that must be resident together (256 CUs x 4)
+constexpr unsigned kSpinLimit = 1u << 20;  // polls of one column before a workgroup gives up
+constexpr int kNoRow = 0x7fffffff;
+
+template <typename T> __device__ __forceinline__ T coherent_load(const T* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T> __device__ __forceinline__ void coherent_store(T* p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long score_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
+__device__ __forceinline__ unsigned long long score_bits(float v) { return (unsigned long long)__float_as_uint(v); }
+__device__ __forceinline__ void score_value(unsigned long long b, double& v) { v = __longlong_as_double((long long)b); }
+__device__ __forceinline__ void score_value(unsigned long long b, float& v) { v = __uint_as_float((unsigned)b); }
+
+// Largest |a| / smallest row over the workgroup, result in every thread; safe to call
+// repeatedly.
+template <typename T> __device__ Candidate<T> block_best_all(T val, int row) {
+  __shared__ T s_val[kRowsPerBlock / 64];
+  __shared__ int s_row[kRowsPerBlock / 64];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const T ov = __shfl_down(val, off, 64);
+    const int orow = __shfl_down(row, off, 64);
+    if (better(ov, orow, val, row)) { val = ov; row = orow; }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { s_val[wave] = val; s_row[wave] = row; }
+  __syncthreads();
+  Candidate<T> c = {s_val[0], s_row[0]};
+#pragma unroll
+  for (int w = 1; w < kRowsPerBlock / 64; ++w)
+    if (better(s_val[w], s_row[w], c.val, c.row)) { c.val = s_val[w]; c.row = s_row[w]; }
+  __syncthreads();
+  return c;
+}
+
+// unblocked_lu (PartialPivLU.h:357-412) of the rows x jbw panel at P, jbw <= 16, in one
+// launch of ceil(rows / 256) workgroups that must all be resident.  Thread = one row, kept
+// in registers from the first load to the final store.  Per column: every workgroup
+// publishes its best candidate together with that candidate's row, polls until all
+// workgroups have published, then every workgroup picks the same winner and the owners of
+// the two rows exchange them.  A workgroup that polls kSpinLimit times without success sets
+// *error and leaves; so does every workgroup that then sees the flag: the grid always drains.
+template <typename T>
+__global__ void __launch_bounds__(kRowsPerBlock)
+    lu_base_fused(T* __restrict__ P, int64_t ld, int rows, int jbw, int size, int* __restrict__ transp,
+                  int row_offset, int col_global, BaseSlot<T>* __restrict__ slots, BaseTop<T>* __restrict__ tops,
+                  unsigned gen0, int* __restrict__ error, int* __restrict__ first_zero, int* __restrict__ nswaps) {
+  __shared__ T s_u[kMaxBase];
+  __shared__ T s_top[kMaxBase];
+  const int nparts = gridDim.x;
+  const int r = blockIdx.x * kRowsPerBlock + threadIdx.x;
+  const bool valid = r < rows;
+  T row[kMaxBase];
+#pragma unroll
+  for (int c = 0; c < kMaxBase; ++c) row[c] = (valid && c < jbw) ? P[r + (int64_t)c * ld] : (T)0;
+
+  for (int jj = 0; jj < size; ++jj) {
+    const unsigned G = gen0 + (unsigned)jj;
+    const unsigned long long parity = (unsigned long long)((G >> 1) & 1u) << 63;
+    BaseSlot<T>* buf = slots + (size_t)(G & 1u) * nparts;
+    BaseTop<T>* top = tops + (G & 1u);
+    // candidate of this workgroup for column jj; no row at or below jj: |a| = 0 at "no row",
+    // which loses every tie
+    T cur = (T)0;
+#pragma unroll
+    for (int c = 0; c < kMaxBase; ++c) cur = c == jj ? row[c] : cur;
+    const bool cand = valid && r >= jj;
+    const Candidate<T> best = block_best_all<T>(cand ? (T)fabs(cur) : (T)-1, cand ? r : kNoRow);
+    const bool have = best.row != kNoRow;
+    if (have ? (valid && r == best.row) : threadIdx.x == 0) {
+      BaseSlot<T>* mine = buf + blockIdx.x;
+      if (have) {
+#pragma unroll
+        for (int c = 0; c < kMaxBase; ++c) coherent_store(&mine->data[c], row[c]);
+        __builtin_amdgcn_s_waitcnt(0);  // the row is out before the words that announce it
+      }
+      coherent_store(&mine->w0, (have ? score_bits(best.val) : 0ull) | parity);
+      coherent_store(&mine->w1, (unsigned long long)(unsigned)best.row | ((unsigned long long)G << 32));
+    }
+    if (valid && r == jj) {
+#pragma unroll
+      for (int c = 0; c < kMaxBase; ++c) coherent_store(&top->data[c], row[c]);
+      __builtin_amdgcn_s_waitcnt(0);
+      coherent_store(&top->tag, (unsigned long long)G);
+    }
+    // wait for every workgroup's words of generation G (and the tag of row jj)
+    T val = (T)-1;
+    int prow = kNoRow;
+    unsigned spins = 0;
+    bool failed = false;
+    for (;;) {
+      bool ready = true;
+      val = (T)-1;
+      prow = kNoRow;
+      for (int i = threadIdx.x; i < nparts; i += kRowsPerBlock) {
+        const unsigned long long w1 = coherent_load(&buf[i].w1);
+        const unsigned long long w0 = coherent_load(&buf[i].w0);
+        if ((unsigned)(w1 >> 32) != G || (w0 & (1ull << 63)) != parity) {
+          ready = false;
+        } else {
+          T v;
+          score_value(w0 & ~(1ull << 63), v);
+          const int rr = (int)(unsigned)w1;
+          if (rr == kNoRow) v = (T)-1;
+          if (better(v, rr, val, prow)) { val = v; prow = rr; }
+        }
+      }
+      if (threadIdx.x == kRowsPerBlock - 1 && coherent_load(&top->tag) != (unsigned long long)G) ready = false;
+      if (__syncthreads_and(ready ? 1 : 0)) break;
+      ++spins;
+      const bool give_up = spins > kSpinLimit || ((spins & 255u) == 0 && coherent_load(error) != 0);
+      if (__syncthreads_or(give_up ? 1 : 0)) { failed = true; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (failed) {
+      if (threadIdx.x == 0) coherent_store(error, 1);
+      break;
+    }
+    // the same winner in every workgroup
+    const Candidate<T> win = block_best_all<T>(val, prow);
+    const bool zero = !(win.val != (T)0);  // exactly zero (or no candidate)
+    const bool swap = !zero && win.row != jj;
+    if (threadIdx.x < kMaxBase) {
+      s_top[threadIdx.x] = coherent_load(&top->data[threadIdx.x]);
+      s_u[threadIdx.x] = swap ? coherent_load(&buf[win.row / kRowsPerBlock].data[threadIdx.x]) : s_top[threadIdx.x];
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      transp[jj] = row_offset + win.row;
+      if (zero) atomicCAS(first_zero, -1, col_global + jj);  // keep the FIRST zero pivot (PartialPivLU.h:391-396)
+      else if (swap) atomicAdd(nswaps, 1);
+    }
+    if (swap && valid) {
+      if (r == win.row) {
+#pragma unroll
+        for (int c = 0; c < kMaxBase; ++c) row[c] = s_top[c];
+      } else if (r == jj) {
+#pragma unroll
+        for (int c = 0; c < kMaxBase; ++c) row[c] = s_u[c];
+      }
+    }
+    if (valid && r > jj) {
+      T pivot = (T)1;
+#pragma unroll
+      for (int c = 0; c < kMaxBase; ++c) pivot = c == jj ? s_u[c] : pivot;
+      T l = (T)0;
+#pragma unroll
+      for (int c = 0; c < kMaxBase; ++c) l = c == jj ? row[c] : l;
+      if (!zero) l = l / pivot;  // the reference divides (lu.col(k).tail /= pivot, :389)
+#pragma unroll
+      for (int c = 0; c < kMaxBase; ++c) {
+        if (c == jj) row[c] = l;
+        else if (c > jj) row[c] = row[c] - l * s_u[c];
+      }
+    }
+    __syncthreads();  // s_u / s_top are rewritten in the next column
+  }
+
+  if (valid) {
+#pragma unroll
+    for (int c = 0; c < kMaxBase; ++c)
+      if (c < jbw) P[r + (int64_t)c * ld] = row[c];
+  }
+}
+
+// After a base case inside a wider panel: the transpositions [k0, k1) (k1 - k0 <= 16) on
+// the other columns of the panel -- `nleft` columns starting at A_left and `nright`
+// columns starting at A_right -- and, on the right-hand ones, the forward substitution
+// with the unit lower triangle L (jb x jb) at rows [k0, k0 + jb).  One thread per column.
+template <typename T>
+__global__ void lu_rowops(T* __restrict__ A_left, int nleft, T* __restrict__ A_right, int nright, int64_t ld,
+                          const int* __restrict__ transp, int k0, int k1, const T* __restrict__ L, int jb) {
+  __shared__ T s_l[kMaxBase * kMaxBase];
+  __shared__ int s_p[kMaxBase];
+  for (int i = threadIdx.x; i < jb * jb; i += blockDim.x)
+    s_l[(i % jb) + (i / jb) * kMaxBase] = L[(i % jb) + (int64_t)(i / jb) * ld];
+  if ((int)threadIdx.x < k1 - k0) s_p[threadIdx.x] = transp[k0 + threadIdx.x];
+  __syncthreads();
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nleft + nright) return;
+  const bool right = c >= nleft;
+  T* col = right ? A_right + (int64_t)(c - nleft) * ld : A_left + (int64_t)c * ld;
+  for (int i = k0; i < k1; ++i) {
+    const int p = s_p[i - k0];
+    if (p != i) {
+      const T t = col[i];
+      col[i] = col[p];
+      col[p] = t;
+    }
+  }
+  if (!right) return;
+  T x[kMaxBase];
+#pragma unroll
+  for (int i = 0; i < kMaxBase; ++i) x[i] = i < jb ? col[k0 + i] : (T)0;
+#pragma unroll
+  for (int i = 0; i < kMaxBase; ++i) {
+    if (i < jb) {
+#pragma unroll
+      for (int rr = i + 1; rr < kMaxBase; ++rr)
+        if (rr < jb) x[rr] -= s_l[rr + i * kMaxBase] * x[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kMaxBase; ++i)
+    if (i < jb) col[k0 + i] = x[i];
+}
+
 // Row transpositions i <-> transp[i], i in [k0, k1), applied in order to `ncols`
 // columns starting at A; one thread per column.  Row indices are global rows of A.
 template <typename T>
@@ -233,6 +470,10 @@ template <typename T> struct Workspace {
   Side<T>* side;
   int* first_zero;
   int* nswaps;
+  BaseSlot<T>* slots;   // 2 x ceil(rows / 256) slots of the fused base case
+  BaseTop<T>* tops;     // 2
+  unsigned* generation; // host-side running count of pivot columns handed to lu_base_fused
+  int* error;
 };
 
 // unblocked_lu (PartialPivLU.h:357-412) on the rows x jbw sub-panel at P.
@@ -241,6 +482,13 @@ hipError_t unblocked(T* P, int64_t ld, int64_t rows, int jbw, int* transp, int r
                      const Workspace<T>& w, hipStream_t s) {
   const int size = (int)std::min<int64_t>(rows, jbw);
   int nparts = (int)((rows + kRowsPerBlock - 1) / kRowsPerBlock);
+  if (nparts <= kMaxFusedParts) {
+    const unsigned gen0 = *w.generation;
+    *w.generation += (unsigned)size;
+    hipLaunchKernelGGL(lu_base_fused<T>, dim3(nparts), dim3(kRowsPerBlock), 0, s, P, ld, (int)rows, jbw, size, transp,
+                       row_offset, col_offset, w.slots, w.tops, gen0, w.error, w.first_zero, w.nswaps);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(lu_colmax<T>, dim3(nparts), dim3(kRowsPerBlock), 0, s, P, ld, 0, (int)rows, 0, w.partials);
   for (int jj = 0; jj < size; ++jj) {
     hipLaunchKernelGGL(lu_pivot<T>, dim3(1), dim3(64), 0, s, P, ld, jbw, jj, w.partials, nparts, transp + jj, row_offset,
@@ -308,6 +556,21 @@ hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows
     const int64_t trows = rows - k - bs, tsize = size - k - bs;
     // the panel [A11; A21], recursively with blocks of 16 (:472-473)
     LU_TRY(blocked<T>(base, ld, row0 + k, col0 + k, trows + bs, bs, transp, 16, w, s));
+    if (bs <= kMaxBase) {
+      // Narrow blocks (inside a panel): the transpositions on both sides (A_0 :479-483, A_2
+      // :488-489) and the triangular solve (:492) in one launch, then the GEMM (:494).
+      const int64_t nright = trows ? tsize : 0;
+      if (k + nright > 0) {
+        hipLaunchKernelGGL(lu_rowops<T>, dim3((unsigned)((k + nright + 63) / 64)), dim3(64), 0, s, base + col0 * ld, (int)k,
+                           base + (col0 + k + bs) * ld, (int)nright, ld, transp, (int)(row0 + k), (int)(row0 + k + bs),
+                           A + k + k * ld, (int)bs);
+        LU_TRY(hipGetLastError());
+      }
+      if (trows)
+        LU_TRY(gemm_minus<T>(trows, tsize, bs, A + (k + bs) + k * ld, A + k + (k + bs) * ld,
+                             A + (k + bs) + (k + bs) * ld, ld, s));
+      continue;
+    }
     // transpositions of the panel on the columns to its left inside this level (A_0, :479-483)
     LU_TRY(laswp<T>(base + col0 * ld, ld, k, transp, (int)(row0 + k), (int)(row0 + k + bs), s));
     if (trows) {
@@ -387,6 +650,8 @@ struct LuScratch {
   std::mutex mu;
   void* buf = nullptr;
   size_t cap = 0;
+  unsigned generation = 2;  // pivot columns handed to lu_base_fused so far (never 0: fresh memory reads 0)
+  int kind = -1;            // element type the exchange area was last used with
   LuStreams streams;
 };
 LuScratch& scratch() {
@@ -400,20 +665,40 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   LuScratch& sc = scratch();
   std::lock_guard<std::mutex> lock(sc.mu);
   const size_t nparts = (size_t)((m + kRowsPerBlock - 1) / kRowsPerBlock) + 1;
-  const size_t need = nparts * sizeof(Candidate<T>) + sizeof(Side<T>) + 256;
+  auto round64 = [](size_t b) { return (b + 63) / 64 * 64; };
+  const size_t off_side = 64;  // first_zero, nswaps, arrived, exited, error live in the first 64 bytes
+  const size_t off_tops = off_side + round64(sizeof(Side<T>));
+  const size_t off_partials = off_tops + round64(2 * sizeof(BaseTop<T>));
+  const size_t off_slots = off_partials + round64(nparts * sizeof(Candidate<T>));
+  const size_t nslots = 2 * std::min<size_t>(nparts, kMaxFusedParts);
+  const size_t need = off_slots + round64(nslots * sizeof(BaseSlot<T>));
   if (need > sc.cap) {
     if (sc.buf) LU_TRY(hipFree(sc.buf));
     sc.buf = nullptr;
     sc.cap = 0;
     LU_TRY(hipMalloc(&sc.buf, need + 4096));
     sc.cap = need + 4096;
+    sc.kind = -1;
+  }
+  // The exchange area of the fused base case is reused from launch to launch without being
+  // cleared (its words carry their generation).  Clear it when its layout changes and
+  // before the generation count could wrap.
+  if (sc.kind != KindOf<T>::value || sc.generation > 0xF0000000u) {
+    LU_TRY(hipMemsetAsync(sc.buf, 0, sc.cap, s));
+    sc.kind = KindOf<T>::value;
+    sc.generation = 2;
   }
   char* p = static_cast<char*>(sc.buf);
   Workspace<T> w;
   w.first_zero = reinterpret_cast<int*>(p);
   w.nswaps = w.first_zero + 1;
-  w.side = reinterpret_cast<Side<T>*>(p + 64);
-  w.partials = reinterpret_cast<Candidate<T>*>(p + 64 + ((sizeof(Side<T>) + 63) / 64) * 64);
+  w.error = reinterpret_cast<int*>(p) + 4;
+  w.generation = &sc.generation;
+  w.side = reinterpret_cast<Side<T>*>(p + off_side);
+  w.tops = reinterpret_cast<BaseTop<T>*>(p + off_tops);
+  w.partials = reinterpret_cast<Candidate<T>*>(p + off_partials);
+  w.slots = reinterpret_cast<BaseSlot<T>*>(p + off_slots);
+  LU_TRY(hipMemsetAsync(p, 0, 64, s));  // error flag of the fused base case
   LU_TRY(hipMemsetAsync(w.first_zero, 0xFF, sizeof(int), s));  // -1
   LU_TRY(hipMemsetAsync(w.nswaps, 0, sizeof(int), s));
   if (!sc.streams.panel) {
@@ -428,11 +713,12 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   } else {  // a panel: nothing to overlap with
     LU_TRY(blocked<T>(A, ld, 0, 0, m, n, d_transp, max_block, w, s));
   }
-  int out[2] = {-1, 0};
+  int out[5] = {-1, 0, 0, 0, 0};
   LU_TRY(hipMemcpyAsync(out, w.first_zero, sizeof out, hipMemcpyDeviceToHost, s));
   LU_TRY(hipStreamSynchronize(s));
   *first_zero_pivot = out[0];
   *nb_transpositions = out[1];
+  if (out[4] != 0) return hipErrorLaunchFailure;  // a workgroup of the fused base case gave up waiting
   return hipSuccess;
 }
 

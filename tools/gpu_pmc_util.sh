@@ -8,7 +8,7 @@ for v in "$@"; do
   IFS=: read name dt n <<< "$v"
   export LD_LIBRARY_PATH=$PWD/build/variants/$name
   for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU" "GRBM_GUI_ACTIVE"; do
-    tag=${name}_${dt}_$(echo $pass | cut -c1-8)
+    tag=${name}-${dt}-${n}_$(echo $pass | cut -c1-8)
     timeout -s KILL 120 rocprofv3 --pmc $pass -d $OUT/$tag -o r -- ./build/gemm_check $dt N N $n $n $n 1 > $OUT/$tag.log 2>&1 || { echo "pass $tag failed"; tail -3 $OUT/$tag.log; }
   done
   echo "$name $dt: $(grep -o 'best=.*TFLOP/s' $OUT/$tag.log)"
