@@ -154,40 +154,64 @@ __global__ void lu_update(T* __restrict__ P, int64_t ld, int rows, int jbw, int 
 //
 // The workgroups of the fused base case agree on each pivot through an exchange area in
 // global memory that is read and written with agent-scope accesses only (they bypass the
-// per-XCD L2, which is not coherent across XCDs).  There is no counter and no atomic
-// read-modify-write: every published word carries the generation it belongs to, and a
-// workgroup simply polls until all words of the current generation are there.
+// per-XCD L2, which is not coherent across XCDs).  There is no counter, no atomic
+// read-modify-write and no ordering between stores: the area is made of 8-byte words, each
+// holding 32 bits of payload and the 32-bit generation it belongs to (an aligned 8-byte
+// store is indivisible), and a reader polls a word until it shows the current generation.
 //
 // Generation G counts pivot columns across launches (the host passes the first G of a
-// launch), buffer G & 1 is used for column G.  Per workgroup and buffer:
-//   w0   = bits of the candidate |a|, bit 63 = (G >> 1) & 1     (|a| >= 0: the bit is free)
-//   w1   = candidate row (low half) | G (high half)
-//   data = the whole panel row of the candidate, written before w0 / w1
-// plus, per buffer, the panel row jj (what the pivot row is swapped with) and its tag G.
+// launch); buffer G & 1 is used for column G.  Per workgroup and buffer: the candidate
+// |a| (1 or 2 words), its row, and the whole panel row of the candidate; per buffer: the
+// panel row jj (what the pivot row is swapped with).
+template <typename T> struct Words {
+  static constexpr int N = sizeof(T) / 4;
+};
 template <typename T> struct BaseSlot {
-  unsigned long long w0;
-  unsigned long long w1;
-  T data[kMaxBase];
+  unsigned long long val[Words<T>::N];
+  unsigned long long row;
+  unsigned long long data[kMaxBase * Words<T>::N];
+  unsigned long long pad[4 - (Words<T>::N + 1) % 4];  // keeps slots 32-byte aligned
 };
 template <typename T> struct BaseTop {
-  T data[kMaxBase];
-  unsigned long long tag;
-  unsigned long long pad;
+  unsigned long long data[kMaxBase * Words<T>::N];
 };
 constexpr int kMaxFusedParts = 1024;   // workgroups that must be resident together (256 CUs x 4)
 constexpr unsigned kSpinLimit = 1u << 20;  // polls of one column before a workgroup gives up
 constexpr int kNoRow = 0x7fffffff;
 
-template <typename T> __device__ __forceinline__ T coherent_load(const T* p) {
+__device__ __forceinline__ unsigned long long coherent_load(const unsigned long long* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-template <typename T> __device__ __forceinline__ void coherent_store(T* p, T v) {
+__device__ __forceinline__ int coherent_load(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void coherent_store(int* p, int v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ unsigned long long score_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
-__device__ __forceinline__ unsigned long long score_bits(float v) { return (unsigned long long)__float_as_uint(v); }
-__device__ __forceinline__ void score_value(unsigned long long b, double& v) { v = __longlong_as_double((long long)b); }
-__device__ __forceinline__ void score_value(unsigned long long b, float& v) { v = __uint_as_float((unsigned)b); }
+__device__ __forceinline__ void put_word(unsigned long long* p, unsigned payload, unsigned G) {
+  __hip_atomic_store(p, (unsigned long long)payload | ((unsigned long long)G << 32), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+// Value -> words and back.
+__device__ __forceinline__ void put_value(unsigned long long* p, double v, unsigned G) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  put_word(p, (unsigned)b, G);
+  put_word(p + 1, (unsigned)(b >> 32), G);
+}
+__device__ __forceinline__ void put_value(unsigned long long* p, float v, unsigned G) {
+  put_word(p, __float_as_uint(v), G);
+}
+// Reads one value; false while any of its words is not of generation G yet.
+__device__ __forceinline__ bool get_value(const unsigned long long* p, double& v, unsigned G) {
+  const unsigned long long lo = coherent_load(p), hi = coherent_load(p + 1);
+  v = __longlong_as_double((long long)((lo & 0xffffffffull) | (hi << 32)));
+  return (unsigned)(lo >> 32) == G && (unsigned)(hi >> 32) == G;
+}
+__device__ __forceinline__ bool get_value(const unsigned long long* p, float& v, unsigned G) {
+  const unsigned long long w = coherent_load(p);
+  v = __uint_as_float((unsigned)w);
+  return (unsigned)(w >> 32) == G;
+}
 
 // Largest |a| / smallest row over the workgroup, result in every thread; safe to call
 // repeatedly.
@@ -234,11 +258,9 @@ __global__ void __launch_bounds__(kRowsPerBlock)
 
   for (int jj = 0; jj < size; ++jj) {
     const unsigned G = gen0 + (unsigned)jj;
-    const unsigned long long parity = (unsigned long long)((G >> 1) & 1u) << 63;
     BaseSlot<T>* buf = slots + (size_t)(G & 1u) * nparts;
     BaseTop<T>* top = tops + (G & 1u);
-    // candidate of this workgroup for column jj; no row at or below jj: |a| = 0 at "no row",
-    // which loses every tie
+    // candidate of this workgroup for column jj ("no row" when all its rows are above jj)
     T cur = (T)0;
 #pragma unroll
     for (int c = 0; c < kMaxBase; ++c) cur = c == jj ? row[c] : cur;
@@ -247,21 +269,18 @@ __global__ void __launch_bounds__(kRowsPerBlock)
     const bool have = best.row != kNoRow;
     if (have ? (valid && r == best.row) : threadIdx.x == 0) {
       BaseSlot<T>* mine = buf + blockIdx.x;
+      put_value(mine->val, best.val, G);
+      put_word(&mine->row, (unsigned)best.row, G);
       if (have) {
 #pragma unroll
-        for (int c = 0; c < kMaxBase; ++c) coherent_store(&mine->data[c], row[c]);
-        __builtin_amdgcn_s_waitcnt(0);  // the row is out before the words that announce it
+        for (int c = 0; c < kMaxBase; ++c) put_value(&mine->data[c * Words<T>::N], row[c], G);
       }
-      coherent_store(&mine->w0, (have ? score_bits(best.val) : 0ull) | parity);
-      coherent_store(&mine->w1, (unsigned long long)(unsigned)best.row | ((unsigned long long)G << 32));
     }
     if (valid && r == jj) {
 #pragma unroll
-      for (int c = 0; c < kMaxBase; ++c) coherent_store(&top->data[c], row[c]);
-      __builtin_amdgcn_s_waitcnt(0);
-      coherent_store(&top->tag, (unsigned long long)G);
+      for (int c = 0; c < kMaxBase; ++c) put_value(&top->data[c * Words<T>::N], row[c], G);
     }
-    // wait for every workgroup's words of generation G (and the tag of row jj)
+    // every workgroup's candidate of generation G
     T val = (T)-1;
     int prow = kNoRow;
     unsigned spins = 0;
@@ -271,19 +290,16 @@ __global__ void __launch_bounds__(kRowsPerBlock)
       val = (T)-1;
       prow = kNoRow;
       for (int i = threadIdx.x; i < nparts; i += kRowsPerBlock) {
-        const unsigned long long w1 = coherent_load(&buf[i].w1);
-        const unsigned long long w0 = coherent_load(&buf[i].w0);
-        if ((unsigned)(w1 >> 32) != G || (w0 & (1ull << 63)) != parity) {
+        T v;
+        const bool okv = get_value(buf[i].val, v, G);
+        const unsigned long long w = coherent_load(&buf[i].row);
+        if (!okv || (unsigned)(w >> 32) != G) {
           ready = false;
         } else {
-          T v;
-          score_value(w0 & ~(1ull << 63), v);
-          const int rr = (int)(unsigned)w1;
-          if (rr == kNoRow) v = (T)-1;
+          const int rr = (int)(unsigned)w;
           if (better(v, rr, val, prow)) { val = v; prow = rr; }
         }
       }
-      if (threadIdx.x == kRowsPerBlock - 1 && coherent_load(&top->tag) != (unsigned long long)G) ready = false;
       if (__syncthreads_and(ready ? 1 : 0)) break;
       ++spins;
       const bool give_up = spins > kSpinLimit || ((spins & 255u) == 0 && coherent_load(error) != 0);
@@ -298,10 +314,31 @@ __global__ void __launch_bounds__(kRowsPerBlock)
     const Candidate<T> win = block_best_all<T>(val, prow);
     const bool zero = !(win.val != (T)0);  // exactly zero (or no candidate)
     const bool swap = !zero && win.row != jj;
-    if (threadIdx.x < kMaxBase) {
-      s_top[threadIdx.x] = coherent_load(&top->data[threadIdx.x]);
-      s_u[threadIdx.x] = swap ? coherent_load(&buf[win.row / kRowsPerBlock].data[threadIdx.x]) : s_top[threadIdx.x];
+    // the two rows: panel row jj, and the winner's row when they are exchanged
+    const unsigned long long* src_top = top->data;
+    const unsigned long long* src_win = buf[swap ? win.row / kRowsPerBlock : 0].data;
+    for (;;) {
+      bool ready = true;
+      if (threadIdx.x < kMaxBase) {
+        T v;
+        ready = get_value(&src_top[threadIdx.x * Words<T>::N], v, G);
+        s_top[threadIdx.x] = v;
+      } else if (threadIdx.x < 2 * kMaxBase && swap) {
+        T v;
+        ready = get_value(&src_win[(threadIdx.x - kMaxBase) * Words<T>::N], v, G);
+        s_u[threadIdx.x - kMaxBase] = v;
+      }
+      if (__syncthreads_and(ready ? 1 : 0)) break;
+      ++spins;
+      const bool give_up = spins > kSpinLimit || ((spins & 255u) == 0 && coherent_load(error) != 0);
+      if (__syncthreads_or(give_up ? 1 : 0)) { failed = true; break; }
+      __builtin_amdgcn_s_sleep(1);
     }
+    if (failed) {
+      if (threadIdx.x == 0) coherent_store(error, 1);
+      break;
+    }
+    if (!swap && threadIdx.x < kMaxBase) s_u[threadIdx.x] = s_top[threadIdx.x];
     __syncthreads();
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       transp[jj] = row_offset + win.row;
