@@ -59,16 +59,16 @@ struct GemmParams {
 // for that pipeline, the divisor d: the LDS writes of the next tile are spread over the
 // first KSTEPS / d k-steps and the global loads over as many k-steps after them.
 #ifndef EIGAMD_F64_SHAPE
-#define EIGAMD_F64_SHAPE 2, 2, 4, 4, 16, 2, 1, 1, 4
+#define EIGAMD_F64_SHAPE 4, 2, 4, 4, 16, 1, 1, 1, 2
 #endif
 #ifndef EIGAMD_F32_SHAPE
 #define EIGAMD_F32_SHAPE 2, 4, 4, 2, 32, 1, 1, 1, 2
 #endif
 #ifndef EIGAMD_C64_SHAPE
-#define EIGAMD_C64_SHAPE 2, 2, 4, 2, 8, 2, 1
+#define EIGAMD_C64_SHAPE 2, 4, 4, 2, 16, 1, 1, 1, 2
 #endif
 #ifndef EIGAMD_C32_SHAPE
-#define EIGAMD_C32_SHAPE 2, 2, 2, 2, 16, 2, 1, 1, 4
+#define EIGAMD_C32_SHAPE 2, 4, 2, 2, 16, 1, 1, 1, 2
 #endif
 
 // Profiling builds can switch stages of the main loop off (results are then wrong; the

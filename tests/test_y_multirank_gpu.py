@@ -80,7 +80,6 @@ def _lu_worker(rank, world, port, n):
     import rng_np
     import eigen_amd
     from eigen_amd.device import DeviceMatrix
-    from eigen_amd import lu as ealu
     from eigen_amd.plu import ColCyclicMatrix, DeviceOps, lu_block_size, pgetrf
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
@@ -108,21 +107,15 @@ def _lu_worker(rank, world, port, n):
                     DeviceOps.gemm_minus(a21, a12, a22)
         transp, nswaps, fz = pgetrf(A, ops, _bcast())
         torch.cuda.synchronize()
-        # single-device factorisation of the same matrix, on rank 0 only (ranks that share
-        # a GPU and each queue thousands of small kernels make the driver time-slice the
-        # card between processes, which is slow): identical pivots, same factors
-        if rank == 0:
-            S = DeviceMatrix(n, n, eigen_amd.F64).fill_uniform(77)
-            t1, nb1, fz1 = ealu.getrf_dev(S)
-            ref_full = torch.from_numpy(S.to_numpy().copy())
-            ref_meta = torch.cat([t1.cpu().to(torch.int64), torch.tensor([nb1, fz1])])
-        else:
-            ref_full = torch.empty((n, n), dtype=torch.float64)
-            ref_meta = torch.empty(n + 2, dtype=torch.int64)
-        dist.broadcast(ref_full, src=0)
-        dist.broadcast(ref_meta, src=0)
-        assert torch.equal(transp.cpu().to(torch.int64), ref_meta[:n])
-        assert nswaps == int(ref_meta[n]) and fz == int(ref_meta[n + 1]) == -1
+        # the CPU restatement of blocked_lu on the same matrix: identical pivots, same
+        # factors.  (No single-device GPU factorisation here: its two-stream look-ahead
+        # stalls for minutes when several processes share one card.)
+        from test_lu_oracle import oracle_lu
+        ref_np = np.asfortranarray(full.copy())
+        t1, nb1, fz1 = oracle_lu(ref_np)
+        assert np.array_equal(transp.cpu().numpy(), t1)
+        assert nswaps == nb1 and fz == fz1 == -1
+        ref_full = torch.from_numpy(ref_np)
         ref = ref_full.numpy()[:, A.global_cols()]
         got = A.local.to_numpy()
         assert np.abs(got - ref).max() <= 64 * np.finfo(np.float64).eps * n * np.abs(ref).max(), rank
@@ -133,4 +126,4 @@ def _lu_worker(rank, world, port, n):
 @pytest.mark.parametrize("world", [2, 4])
 def test_pgetrf_real_device_steps(world):
     """Distributed LU with the library's own panel / swap / solve / GEMM entry points."""
-    mp.spawn(_lu_worker, args=(world, _free_port(), 2048), nprocs=world, join=True)
+    mp.spawn(_lu_worker, args=(world, _free_port(), 1024), nprocs=world, join=True)
