@@ -18,7 +18,9 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <mutex>
+#include <vector>
 
 #include "gemm_launch.hpp"
 #include "lu.hpp"
@@ -166,11 +168,15 @@ __global__ void lu_update(T* __restrict__ P, int64_t ld, int rows, int jbw, int 
 template <typename T> struct Words {
   static constexpr int N = sizeof(T) / 4;
 };
-template <typename T> struct BaseSlot {
+// Slots are padded to EIGAMD_LU_SLOT_BYTES so that the polls of all workgroups spread over
+// the memory channels instead of queueing on the few that a dense array would map to.
+#ifndef EIGAMD_LU_SLOT_BYTES
+#define EIGAMD_LU_SLOT_BYTES 1024
+#endif
+template <typename T> struct alignas(EIGAMD_LU_SLOT_BYTES) BaseSlot {
   unsigned long long val[Words<T>::N];
   unsigned long long row;
   unsigned long long data[kMaxBase * Words<T>::N];
-  unsigned long long pad[4 - (Words<T>::N + 1) % 4];  // keeps slots 32-byte aligned
 };
 template <typename T> struct BaseTop {
   unsigned long long data[kMaxBase * Words<T>::N];
@@ -243,7 +249,7 @@ template <typename T> __device__ Candidate<T> block_best_all(T val, int row) {
 // the two rows exchange them.  A workgroup that polls kSpinLimit times without success sets
 // *error and leaves; so does every workgroup that then sees the flag: the grid always drains.
 template <typename T>
-__global__ void __launch_bounds__(kRowsPerBlock)
+__global__ void __launch_bounds__(kRowsPerBlock, 4)
     lu_base_fused(T* __restrict__ P, int64_t ld, int rows, int jbw, int size, int* __restrict__ transp,
                   int row_offset, int col_global, BaseSlot<T>* __restrict__ slots, BaseTop<T>* __restrict__ tops,
                   unsigned gen0, int* __restrict__ error, int* __restrict__ first_zero, int* __restrict__ nswaps) {
@@ -311,8 +317,12 @@ __global__ void __launch_bounds__(kRowsPerBlock)
       break;
     }
     // the same winner in every workgroup
-    const Candidate<T> win = block_best_all<T>(val, prow);
-    const bool zero = !(win.val != (T)0);  // exactly zero (or no candidate)
+    Candidate<T> win = block_best_all<T>(val, prow);
+    if (win.row == kNoRow) {  // nothing comparable in the column (NaNs): no exchange, pivot = the diagonal entry
+      win.row = jj;
+      win.val = (T)1;
+    }
+    const bool zero = !(win.val != (T)0);  // exactly zero
     const bool swap = !zero && win.row != jj;
     // the two rows: panel row jj, and the winner's row when they are exchanged
     const unsigned long long* src_top = top->data;
@@ -420,6 +430,13 @@ __global__ void lu_rowops(T* __restrict__ A_left, int nleft, T* __restrict__ A_r
     if (i < jb) col[k0 + i] = x[i];
 }
 
+// transp[i] = i: every entry is a valid (identity) transposition before the factorisation
+// fills it in, whatever happens to the kernels in between.
+__global__ void lu_iota(int* __restrict__ transp, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) transp[i] = i;
+}
+
 // Row transpositions i <-> transp[i], i in [k0, k1), applied in order to `ncols`
 // columns starting at A; one thread per column.  Row indices are global rows of A.
 template <typename T>
@@ -434,6 +451,93 @@ __global__ void lu_laswp(T* __restrict__ A, int64_t ld, int ncols, const int* __
       col[i] = col[p];
       col[p] = t;
     }
+  }
+}
+
+// ---- many transpositions at once ----------------------------------------------------
+//
+// A run of transpositions i <-> transp[i], i in [k0, k1), k1 - k0 <= kPlanSpan, applied in
+// order is a permutation of at most 2 (k1 - k0) rows.  lu_swap_plan works it out once (one
+// wavefront follows the run) as a list of moves "row dst receives what row src held";
+// lu_apply_plan then moves whole row segments with independent loads, instead of one
+// dependent load-store pair per transposition and column.
+constexpr int kPlanSpan = 256;
+struct SwapPlan {
+  int count;
+  int dst[2 * kPlanSpan];
+  int src[2 * kPlanSpan];
+};
+
+__global__ void __launch_bounds__(64) lu_swap_plan(const int* __restrict__ transp, int k0, int k1, SwapPlan* __restrict__ plan) {
+  __shared__ int s_top[kPlanSpan];    // row whose original content now sits at row k0 + t
+  __shared__ int s_orow[kPlanSpan];   // rows outside [k0, k1) that took part
+  __shared__ int s_osrc[kPlanSpan];   // ... and whose original content they hold now
+  __shared__ int s_p[kPlanSpan];
+  __shared__ int s_found;
+  const int lane = threadIdx.x;
+  const int span = k1 - k0;
+  for (int t = lane; t < span; t += 64) {
+    s_top[t] = k0 + t;
+    s_p[t] = transp[k0 + t];
+  }
+  __syncthreads();
+  int nout = 0;
+  for (int i = 0; i < span; ++i) {
+    const int p = s_p[i];
+    if (p == k0 + i) continue;
+    if (p >= k0 && p < k1) {
+      if (lane == 0) {
+        const int t = s_top[i];
+        s_top[i] = s_top[p - k0];
+        s_top[p - k0] = t;
+      }
+    } else {
+      if (lane == 0) s_found = -1;
+      __syncthreads();
+      for (int j = lane; j < nout; j += 64)
+        if (s_orow[j] == p) s_found = j;
+      __syncthreads();
+      int idx = s_found;
+      if (idx < 0) {
+        idx = nout++;
+        if (lane == 0) { s_orow[idx] = p; s_osrc[idx] = p; }
+      }
+      if (lane == 0) {
+        const int t = s_top[i];
+        s_top[i] = s_osrc[idx];
+        s_osrc[idx] = t;
+      }
+    }
+    __syncthreads();
+  }
+  // compact the moves that change something; one lane keeps the order simple
+  if (lane == 0) {
+    int n = 0;
+    for (int t = 0; t < span; ++t)
+      if (s_top[t] != k0 + t) { plan->dst[n] = k0 + t; plan->src[n] = s_top[t]; ++n; }
+    for (int j = 0; j < nout; ++j)
+      if (s_osrc[j] != s_orow[j]) { plan->dst[n] = s_orow[j]; plan->src[n] = s_osrc[j]; ++n; }
+    plan->count = n;
+  }
+}
+
+// Applies a plan to `ncols` columns starting at A; a workgroup owns kPlanCols columns and
+// stages the moved elements in LDS (every load happens before any store of the workgroup).
+constexpr int kPlanCols = 8;
+template <typename T>
+__global__ void __launch_bounds__(256) lu_apply_plan(T* __restrict__ A, int64_t ld, int ncols, const SwapPlan* __restrict__ plan) {
+  __shared__ T s_val[2 * kPlanSpan * kPlanCols];
+  const int n = plan->count;
+  const int c0 = blockIdx.x * kPlanCols;
+  const int nc = min(kPlanCols, ncols - c0);
+  for (int idx = threadIdx.x; idx < n * nc; idx += 256) {
+    const int c = idx / n, j = idx - c * n;
+    s_val[idx] = A[plan->src[j] + (int64_t)(c0 + c) * ld];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < n * nc; idx += 256) {
+    const int c = idx / n, j = idx - c * n;
+    A[plan->dst[j] + (int64_t)(c0 + c) * ld] = s_val[idx];
   }
 }
 
@@ -511,6 +615,8 @@ template <typename T> struct Workspace {
   BaseTop<T>* tops;     // 2
   unsigned* generation; // host-side running count of pivot columns handed to lu_base_fused
   int* error;
+  int fused_capacity;   // workgroups of lu_base_fused that are certainly resident together
+  SwapPlan* plan;       // scratch of lu_swap_plan / lu_apply_plan
 };
 
 // unblocked_lu (PartialPivLU.h:357-412) on the rows x jbw sub-panel at P.
@@ -519,7 +625,7 @@ hipError_t unblocked(T* P, int64_t ld, int64_t rows, int jbw, int* transp, int r
                      const Workspace<T>& w, hipStream_t s) {
   const int size = (int)std::min<int64_t>(rows, jbw);
   int nparts = (int)((rows + kRowsPerBlock - 1) / kRowsPerBlock);
-  if (nparts <= kMaxFusedParts) {
+  if (nparts <= w.fused_capacity) {
     const unsigned gen0 = *w.generation;
     *w.generation += (unsigned)size;
     hipLaunchKernelGGL(lu_base_fused<T>, dim3(nparts), dim3(kRowsPerBlock), 0, s, P, ld, (int)rows, jbw, size, transp,
@@ -540,11 +646,31 @@ hipError_t unblocked(T* P, int64_t ld, int64_t rows, int jbw, int* transp, int r
   return hipGetLastError();
 }
 
-template <typename T>
-hipError_t laswp(T* A, int64_t ld, int64_t ncols, const int* transp, int k0, int k1, hipStream_t s) {
-  if (ncols <= 0 || k1 <= k0) return hipSuccess;
-  hipLaunchKernelGGL(lu_laswp<T>, dim3((unsigned)((ncols + 127) / 128)), dim3(128), 0, s, A, ld, (int)ncols, transp, k0, k1);
+hipError_t make_plan(const int* transp, int k0, int k1, SwapPlan* plan, hipStream_t s) {
+  hipLaunchKernelGGL(lu_swap_plan, dim3(1), dim3(64), 0, s, transp, k0, k1, plan);
   return hipGetLastError();
+}
+template <typename T> hipError_t apply_plan(T* A, int64_t ld, int64_t ncols, const SwapPlan* plan, hipStream_t s) {
+  if (ncols <= 0) return hipSuccess;
+  hipLaunchKernelGGL(lu_apply_plan<T>, dim3((unsigned)((ncols + kPlanCols - 1) / kPlanCols)), dim3(256), 0, s, A, ld,
+                     (int)ncols, plan);
+  return hipGetLastError();
+}
+
+// Short runs: one thread per column applies them one after the other.  Long runs: by plan,
+// kPlanSpan transpositions at a time (`plan` is device scratch of the calling stream).
+template <typename T>
+hipError_t laswp(T* A, int64_t ld, int64_t ncols, const int* transp, int k0, int k1, SwapPlan* plan, hipStream_t s) {
+  if (ncols <= 0 || k1 <= k0) return hipSuccess;
+  if (k1 - k0 <= 32 || plan == nullptr) {
+    hipLaunchKernelGGL(lu_laswp<T>, dim3((unsigned)((ncols + 127) / 128)), dim3(128), 0, s, A, ld, (int)ncols, transp, k0, k1);
+    return hipGetLastError();
+  }
+  for (int k = k0; k < k1; k += kPlanSpan) {
+    LU_TRY(make_plan(transp, k, std::min(k + kPlanSpan, k1), plan, s));
+    LU_TRY(apply_plan<T>(A, ld, ncols, plan, s));
+  }
+  return hipSuccess;
 }
 
 // B (bs x ncols) <- L^-1 B with L the unit lower triangle of the bs x bs block at L:
@@ -581,7 +707,7 @@ hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows
     const int jbw = (int)std::min<int64_t>(cols, rows);
     LU_TRY(unblocked<T>(A, ld, rows, jbw, transp + row0, (int)row0, (int)col0, w, s));
     if (cols > jbw) {
-      LU_TRY(laswp<T>(base + (col0 + jbw) * ld, ld, cols - jbw, transp, (int)row0, (int)(row0 + jbw), s));
+      LU_TRY(laswp<T>(base + (col0 + jbw) * ld, ld, cols - jbw, transp, (int)row0, (int)(row0 + jbw), w.plan, s));
       hipLaunchKernelGGL((lu_trsm_small<T, kMaxBase>), dim3((unsigned)((cols - jbw + 63) / 64)), dim3(64), 0, s, A, ld,
                          A + (int64_t)jbw * ld, ld, jbw, (int)(cols - jbw));
     }
@@ -609,10 +735,10 @@ hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows
       continue;
     }
     // transpositions of the panel on the columns to its left inside this level (A_0, :479-483)
-    LU_TRY(laswp<T>(base + col0 * ld, ld, k, transp, (int)(row0 + k), (int)(row0 + k + bs), s));
+    LU_TRY(laswp<T>(base + col0 * ld, ld, k, transp, (int)(row0 + k), (int)(row0 + k + bs), w.plan, s));
     if (trows) {
       // ... and on the columns to its right (A_2, :488-489)
-      LU_TRY(laswp<T>(base + (col0 + k + bs) * ld, ld, tsize, transp, (int)(row0 + k), (int)(row0 + k + bs), s));
+      LU_TRY(laswp<T>(base + (col0 + k + bs) * ld, ld, tsize, transp, (int)(row0 + k), (int)(row0 + k + bs), w.plan, s));
       T* A11 = A + k + k * ld;
       T* A12 = A + k + (k + bs) * ld;
       T* A21 = A + (k + bs) + k * ld;
@@ -639,8 +765,12 @@ hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows
 //    the update stream, behind that GEMM.
 struct LuStreams {
   hipStream_t panel = nullptr;
+  hipStream_t update = nullptr;    // null: the caller's stream does the updates
   hipEvent_t ready = nullptr;      // update -> panel: next panel's columns are current
   hipEvent_t factored = nullptr;   // panel -> update: panel factorised, transpositions known
+  hipEvent_t fork = nullptr;       // caller's stream -> update stream
+  hipEvent_t join = nullptr;       // update stream -> caller's stream
+  int panel_cus = 0;               // CUs set aside for the panel stream (0: none, streams share the chip)
 };
 
 template <typename T>
@@ -650,6 +780,12 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
   if (size <= kMaxBase) return blocked<T>(A, ld, 0, 0, rows, cols, transp, max_block, w, upd);
   const int64_t block = block_size_rule(size, max_block);
   hipStream_t pan = st.panel;
+  hipStream_t caller = upd;
+  if (st.update) {  // the updates run on the stream that leaves the panel's CUs alone
+    LU_TRY(hipEventRecord(st.fork, caller));
+    LU_TRY(hipStreamWaitEvent(st.update, st.fork, 0));
+    upd = st.update;
+  }
   LU_TRY(hipEventRecord(st.ready, upd));  // everything queued before the call
   for (int64_t k = 0; k < size; k += block) {
     const int64_t bs = std::min(size - k, block);
@@ -663,23 +799,32 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
     T* A21 = A + (k + bs) + k * ld;
     // columns of the next panel first
     const int64_t nb = trows ? std::min<int64_t>(tsize, block) : 0;
+    const bool planned = bs > 32 && bs <= kPlanSpan;  // one plan serves the three column ranges of this step
+    if (planned) LU_TRY(make_plan(transp, k0, k1, w.plan, upd));
+    auto swap_rows = [&](T* cols, int64_t ncols) {
+      return planned ? apply_plan<T>(cols, ld, ncols, w.plan, upd) : laswp<T>(cols, ld, ncols, transp, k0, k1, w.plan, upd);
+    };
     if (nb > 0) {
       T* A12 = A + k + (k + bs) * ld;
-      LU_TRY(laswp<T>(A + (k + bs) * ld, ld, nb, transp, k0, k1, upd));
+      LU_TRY(swap_rows(A + (k + bs) * ld, nb));
       LU_TRY(trsm_unit_lower<T>(A11, A12, ld, bs, nb, upd));
       LU_TRY(gemm_minus<T>(trows, nb, bs, A21, A12, A12 + bs, ld, upd));
     }
     LU_TRY(hipEventRecord(st.ready, upd));
     // columns to the left (A_0), then the rest of the trailing matrix (A_2)
-    LU_TRY(laswp<T>(A, ld, k, transp, k0, k1, upd));
+    LU_TRY(swap_rows(A, k));
     if (trows && tsize > nb) {
       T* A12 = A + k + (k + bs + nb) * ld;
-      LU_TRY(laswp<T>(A + (k + bs + nb) * ld, ld, tsize - nb, transp, k0, k1, upd));
+      LU_TRY(swap_rows(A + (k + bs + nb) * ld, tsize - nb));
       LU_TRY(trsm_unit_lower<T>(A11, A12, ld, bs, tsize - nb, upd));
       LU_TRY(gemm_minus<T>(trows, tsize - nb, bs, A21, A12, A12 + bs, ld, upd));
     }
   }
   // the panel stream has nothing queued after the last `factored` event
+  if (st.update) {
+    LU_TRY(hipEventRecord(st.join, upd));
+    LU_TRY(hipStreamWaitEvent(caller, st.join, 0));
+  }
   return hipSuccess;
 }
 
@@ -689,11 +834,65 @@ struct LuScratch {
   size_t cap = 0;
   unsigned generation = 2;  // pivot columns handed to lu_base_fused so far (never 0: fresh memory reads 0)
   int kind = -1;            // element type the exchange area was last used with
+  void* pub_plan = nullptr; // plan scratch of laswp_device
+  hipEvent_t pub_plan_done = nullptr;
   LuStreams streams;
 };
 LuScratch& scratch() {
   static LuScratch s;
   return s;
+}
+
+// Streams of the look-ahead.  When the chip has CUs to spare (EIGAMD_LU_PANEL_CUS, default
+// 32 of 256; 0 switches this off) the panel stream owns `panel_cus` compute units and the
+// update stream the others, so the many short kernels of a panel never queue behind the
+// workgroups of the trailing GEMM.  Bit b of a CU mask is compute unit b / 8 of XCD b % 8, so
+// a run of bits takes the same number of CUs from every XCD.  The fused base case needs all
+// its workgroups resident (`per_cu` fit on a CU): a taller panel gets more CUs.
+hipError_t make_streams(LuStreams& st, int base_workgroups, int per_cu, int* total_cus) {
+  int want = 32;
+  if (const char* e = getenv("EIGAMD_LU_PANEL_CUS")) want = atoi(e);
+  hipDeviceProp_t prop;
+  int dev = 0;
+  LU_TRY(hipGetDevice(&dev));
+  LU_TRY(hipGetDeviceProperties(&prop, dev));
+  const int total = prop.multiProcessorCount;
+  *total_cus = total;
+  if (want > 0) {
+    want = std::max(want, (base_workgroups + per_cu - 1) / per_cu);
+    want = (want + 7) / 8 * 8;
+    if (total % 32 != 0 || want * 2 > total) want = 0;  // not worth splitting: share the chip
+  }
+  if (st.panel && st.panel_cus == want) return hipSuccess;
+  if (st.panel) {
+    LU_TRY(hipStreamSynchronize(st.panel));
+    LU_TRY(hipStreamDestroy(st.panel));
+    st.panel = nullptr;
+    if (st.update) {
+      LU_TRY(hipStreamSynchronize(st.update));
+      LU_TRY(hipStreamDestroy(st.update));
+      st.update = nullptr;
+    }
+  }
+  if (!st.ready) {
+    LU_TRY(hipEventCreateWithFlags(&st.ready, hipEventDisableTiming));
+    LU_TRY(hipEventCreateWithFlags(&st.factored, hipEventDisableTiming));
+    LU_TRY(hipEventCreateWithFlags(&st.fork, hipEventDisableTiming));
+    LU_TRY(hipEventCreateWithFlags(&st.join, hipEventDisableTiming));
+  }
+  if (want == 0) {
+    int lo = 0, hi = 0;
+    LU_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    LU_TRY(hipStreamCreateWithPriority(&st.panel, hipStreamNonBlocking, hi));
+  } else {
+    const int words = total / 32;
+    std::vector<uint32_t> pmask(words, 0u), umask(words, 0u);
+    for (int b = 0; b < total; ++b) (b >= total - want ? pmask : umask)[b / 32] |= 1u << (b % 32);
+    LU_TRY(hipExtStreamCreateWithCUMask(&st.panel, (uint32_t)words, pmask.data()));
+    LU_TRY(hipExtStreamCreateWithCUMask(&st.update, (uint32_t)words, umask.data()));
+  }
+  st.panel_cus = want;
+  return hipSuccess;
 }
 
 template <typename T>
@@ -705,7 +904,8 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   auto round64 = [](size_t b) { return (b + 63) / 64 * 64; };
   const size_t off_side = 64;  // first_zero, nswaps, arrived, exited, error live in the first 64 bytes
   const size_t off_tops = off_side + round64(sizeof(Side<T>));
-  const size_t off_partials = off_tops + round64(2 * sizeof(BaseTop<T>));
+  const size_t off_plan = off_tops + round64(2 * sizeof(BaseTop<T>));
+  const size_t off_partials = off_plan + round64(sizeof(SwapPlan));
   const size_t off_slots = off_partials + round64(nparts * sizeof(Candidate<T>));
   const size_t nslots = 2 * std::min<size_t>(nparts, kMaxFusedParts);
   const size_t need = off_slots + round64(nslots * sizeof(BaseSlot<T>));
@@ -733,17 +933,30 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   w.generation = &sc.generation;
   w.side = reinterpret_cast<Side<T>*>(p + off_side);
   w.tops = reinterpret_cast<BaseTop<T>*>(p + off_tops);
+  w.plan = reinterpret_cast<SwapPlan*>(p + off_plan);
   w.partials = reinterpret_cast<Candidate<T>*>(p + off_partials);
   w.slots = reinterpret_cast<BaseSlot<T>*>(p + off_slots);
   LU_TRY(hipMemsetAsync(p, 0, 64, s));  // error flag of the fused base case
   LU_TRY(hipMemsetAsync(w.first_zero, 0xFF, sizeof(int), s));  // -1
   LU_TRY(hipMemsetAsync(w.nswaps, 0, sizeof(int), s));
-  if (!sc.streams.panel) {
-    int lo = 0, hi = 0;
-    LU_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    LU_TRY(hipStreamCreateWithPriority(&sc.streams.panel, hipStreamNonBlocking, hi));
-    LU_TRY(hipEventCreateWithFlags(&sc.streams.ready, hipEventDisableTiming));
-    LU_TRY(hipEventCreateWithFlags(&sc.streams.factored, hipEventDisableTiming));
+  int per_cu = 0, total_cus = 0;
+  LU_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lu_base_fused<T>, kRowsPerBlock, 0));
+  per_cu = std::max(per_cu, 1);
+  if (max_block > 16) {
+    LU_TRY(make_streams(sc.streams, (int)(nparts - 1), per_cu, &total_cus));
+  } else {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    LU_TRY(hipGetDevice(&dev));
+    LU_TRY(hipGetDeviceProperties(&prop, dev));
+    total_cus = prop.multiProcessorCount;
+  }
+  const int panel_cus = (max_block > 16 && sc.streams.panel_cus > 0) ? sc.streams.panel_cus : total_cus;
+  w.fused_capacity = std::min(kMaxFusedParts, per_cu * panel_cus);
+  {
+    const int nt = (int)std::min(m, n);
+    if (nt > 0) hipLaunchKernelGGL(lu_iota, dim3((nt + 255) / 256), dim3(256), 0, s, d_transp, nt);
+    LU_TRY(hipGetLastError());
   }
   if (max_block > 16) {
     LU_TRY(blocked_lookahead<T>(A, ld, m, n, d_transp, max_block, w, sc.streams, s));
@@ -775,9 +988,21 @@ hipError_t getrf_device(int kind, int64_t m, int64_t n, void* A, int64_t ld, int
 
 hipError_t laswp_device(int kind, void* A, int64_t ld, int64_t ncols, const int* d_transp, int k0, int k1,
                         hipStream_t s) {
-  if (kind == F64) return laswp<double>(static_cast<double*>(A), ld, ncols, d_transp, k0, k1, s);
-  if (kind == F32) return laswp<float>(static_cast<float*>(A), ld, ncols, d_transp, k0, k1, s);
-  return hipErrorInvalidValue;
+  if (kind != F64 && kind != F32) return hipErrorInvalidValue;
+  // The plan scratch is shared by all callers: a use waits for the previous one to finish.
+  LuScratch& sc = scratch();
+  std::lock_guard<std::mutex> lock(sc.mu);
+  if (!sc.pub_plan) {
+    LU_TRY(hipMalloc(&sc.pub_plan, sizeof(SwapPlan)));
+    LU_TRY(hipEventCreateWithFlags(&sc.pub_plan_done, hipEventDisableTiming));
+  } else {
+    LU_TRY(hipStreamWaitEvent(s, sc.pub_plan_done, 0));
+  }
+  SwapPlan* plan = static_cast<SwapPlan*>(sc.pub_plan);
+  hipError_t e = kind == F64 ? laswp<double>(static_cast<double*>(A), ld, ncols, d_transp, k0, k1, plan, s)
+                             : laswp<float>(static_cast<float*>(A), ld, ncols, d_transp, k0, k1, plan, s);
+  LU_TRY(e);
+  return hipEventRecord(sc.pub_plan_done, s);
 }
 
 hipError_t trsm_llnu_device(int kind, int64_t bs, int64_t ncols, const void* L, int64_t ldl, void* B, int64_t ldb,
