@@ -567,6 +567,72 @@ __global__ void lu_trsm_small(const T* __restrict__ L, int64_t ldl, T* __restric
     if (i < jb) col[i] = x[i];
 }
 
+// X = L^-1 for the unit lower triangle L of a bs x bs block (bs <= kPlanSpan), written as a
+// full bs x bs matrix (zeros above the diagonal) with leading dimension bs.  A workgroup
+// owns 32 columns of X, kept in LDS, and walks down the rows 32 at a time: first the part of
+// the inner products that only needs rows already done (all 32 x 32 results in parallel,
+// independent loads of L), then the 32 x 32 triangle on the diagonal from LDS, one thread
+// per column.
+constexpr int kInvCols = 32;
+template <typename T>
+__global__ void __launch_bounds__(256) lu_trtri(const T* __restrict__ L, int64_t ldl, int bs, T* __restrict__ X) {
+  __shared__ T s_x[kInvCols][kPlanSpan + 1];   // s_x[c][i]: row i of this workgroup's column c
+  __shared__ T s_acc[kInvCols][kInvCols + 1];  // s_acc[c][i - i0]
+  __shared__ T s_d[kInvCols][kInvCols + 1];    // s_d[k - i0][i - i0] = L(i, k) of the diagonal block
+  const int first = blockIdx.x * kInvCols;      // first column of this workgroup: rows above it are zero
+  for (int idx = threadIdx.x; idx < kInvCols * bs; idx += 256) s_x[idx / bs][idx % bs] = (T)0;
+  __syncthreads();
+  const int il = threadIdx.x % kInvCols;        // row inside the row block
+  const int cg = threadIdx.x / kInvCols;        // 8 groups of 4 columns
+  for (int i0 = first; i0 < bs; i0 += kInvCols) {
+    const int i = i0 + il;
+    // (a) acc[c][i] = sum over finished rows k in [first, i0) of L(i, k) * x[c][k]
+    T acc[4] = {(T)0, (T)0, (T)0, (T)0};
+    if (i < bs) {
+      // i0 - first is a multiple of 32: batches of 16 independent loads
+      for (int k = first; k < i0; k += 16) {
+        T l[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) l[u] = L[i + (int64_t)(k + u) * ldl];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] += l[u] * s_x[cg * 4 + q][k + u];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s_acc[cg * 4 + q][il] = acc[q];
+    // the diagonal block of L
+    for (int idx = threadIdx.x; idx < kInvCols * kInvCols; idx += 256) {
+      const int kk = idx / kInvCols, ii = idx % kInvCols;
+      s_d[kk][ii] = (i0 + ii < bs && i0 + kk < bs && ii > kk) ? L[(i0 + ii) + (int64_t)(i0 + kk) * ldl] : (T)0;
+    }
+    __syncthreads();
+    // (b) the triangle: thread c walks rows i0 .. i0+31 of its column
+    if (threadIdx.x < kInvCols) {
+      const int c = threadIdx.x, g = first + c;
+      T x[kInvCols];
+#pragma unroll
+      for (int ii = 0; ii < kInvCols; ++ii) {
+        T v = s_acc[c][ii];
+#pragma unroll
+        for (int kk = 0; kk < kInvCols; ++kk)
+          if (kk < ii) v += s_d[kk][ii] * x[kk];
+        const int row = i0 + ii;
+        x[ii] = (g >= bs || row >= bs || row < g) ? (T)0 : (row == g ? (T)1 : -v);
+      }
+#pragma unroll
+      for (int ii = 0; ii < kInvCols; ++ii)
+        if (i0 + ii < bs) s_x[c][i0 + ii] = x[ii];
+    }
+    __syncthreads();
+  }
+  for (int idx = threadIdx.x; idx < kInvCols * bs; idx += 256) {
+    const int c = idx / bs, i = idx % bs;
+    if (first + c < bs) X[i + (int64_t)(first + c) * bs] = s_x[c][i];
+  }
+}
+
 template <typename T> struct KindOf;
 template <> struct KindOf<float> { static constexpr int value = F32; };
 template <> struct KindOf<double> { static constexpr int value = F64; };
@@ -588,6 +654,22 @@ template <typename T> hipError_t gemm_minus3(int64_t m, int64_t n, int64_t k, co
   c.m = m; c.n = n; c.k = k;
   c.alpha[0] = -1.0; c.alpha[1] = 0.0;
   c.beta[0] = 1.0; c.beta[1] = 0.0;
+  c.A = A; c.lda = lda;
+  c.B = B; c.ldb = ldb;
+  c.C = C; c.ldc = ldc;
+  return KindOf<T>::value == F64 ? launch_gemm_f64(c, s) : launch_gemm_f32(c, s);
+}
+
+// C = A * B (alpha = 1, beta = 0).
+template <typename T> hipError_t gemm_assign(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B, int64_t ldb,
+                                             T* C, int64_t ldc, hipStream_t s) {
+  if (m <= 0 || n <= 0) return hipSuccess;
+  GemmCall c;
+  c.kind = KindOf<T>::value;
+  c.opa = OP_N; c.opb = OP_N;
+  c.m = m; c.n = n; c.k = k;
+  c.alpha[0] = 1.0; c.alpha[1] = 0.0;
+  c.beta[0] = 0.0; c.beta[1] = 0.0;
   c.A = A; c.lda = lda;
   c.B = B; c.ldb = ldb;
   c.C = C; c.ldc = ldc;
@@ -616,7 +698,8 @@ template <typename T> struct Workspace {
   unsigned* generation; // host-side running count of pivot columns handed to lu_base_fused
   int* error;
   int fused_capacity;   // workgroups of lu_base_fused that are certainly resident together
-  SwapPlan* plan;       // scratch of lu_swap_plan / lu_apply_plan
+  SwapPlan* plan[2];    // scratch of lu_swap_plan / lu_apply_plan (alternating per look-ahead step)
+  T* linv[2];           // inverse of the current step's unit lower triangle, kPlanSpan^2 each
 };
 
 // unblocked_lu (PartialPivLU.h:357-412) on the rows x jbw sub-panel at P.
@@ -692,6 +775,20 @@ hipError_t trsm_unit_lower(const T* L, T* B, int64_t ld, int64_t bs, int64_t nco
   return trsm_unit_lower2<T>(L, ld, B, ld, bs, ncols, s);
 }
 
+// The same solve as ONE product with the explicit inverse of the triangle (|l_ij| <= 1 under
+// partial pivoting): B <- X * B, in place.  In place is safe because the whole row extent
+// fits one tile row of the GEMM (bs <= BM): a workgroup reads only the columns of B that it
+// overwrites, and it reads all of them before its epilogue stores.
+template <typename T> constexpr int gemm_tile_rows() { return Geometry<KindOf<T>::value>::BM; }
+template <typename T> hipError_t make_inverse(const T* L, int64_t ldl, int64_t bs, T* X, hipStream_t s) {
+  hipLaunchKernelGGL(lu_trtri<T>, dim3((unsigned)((bs + kInvCols - 1) / kInvCols)), dim3(256), 0, s, L, ldl, (int)bs, X);
+  return hipGetLastError();
+}
+template <typename T> bool inverse_applies(int64_t bs) { return bs > 32 && bs <= kPlanSpan && bs <= gemm_tile_rows<T>(); }
+template <typename T> hipError_t apply_inverse(const T* X, int64_t bs, T* B, int64_t ldb, int64_t ncols, hipStream_t s) {
+  return gemm_assign<T>(bs, ncols, bs, X, bs, B, ldb, B, ldb, s);
+}
+
 // blocked_lu (PartialPivLU.h:429-498).  A points at the (row0, row0) corner of the
 // enclosing matrix `base`; transposition entries are written as GLOBAL row indices of
 // `base`, so the caller-level "+= k" of the reference (:481) is already applied.
@@ -707,7 +804,7 @@ hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows
     const int jbw = (int)std::min<int64_t>(cols, rows);
     LU_TRY(unblocked<T>(A, ld, rows, jbw, transp + row0, (int)row0, (int)col0, w, s));
     if (cols > jbw) {
-      LU_TRY(laswp<T>(base + (col0 + jbw) * ld, ld, cols - jbw, transp, (int)row0, (int)(row0 + jbw), w.plan, s));
+      LU_TRY(laswp<T>(base + (col0 + jbw) * ld, ld, cols - jbw, transp, (int)row0, (int)(row0 + jbw), w.plan[0], s));
       hipLaunchKernelGGL((lu_trsm_small<T, kMaxBase>), dim3((unsigned)((cols - jbw + 63) / 64)), dim3(64), 0, s, A, ld,
                          A + (int64_t)jbw * ld, ld, jbw, (int)(cols - jbw));
     }
@@ -735,15 +832,20 @@ hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows
       continue;
     }
     // transpositions of the panel on the columns to its left inside this level (A_0, :479-483)
-    LU_TRY(laswp<T>(base + col0 * ld, ld, k, transp, (int)(row0 + k), (int)(row0 + k + bs), w.plan, s));
+    LU_TRY(laswp<T>(base + col0 * ld, ld, k, transp, (int)(row0 + k), (int)(row0 + k + bs), w.plan[0], s));
     if (trows) {
       // ... and on the columns to its right (A_2, :488-489)
-      LU_TRY(laswp<T>(base + (col0 + k + bs) * ld, ld, tsize, transp, (int)(row0 + k), (int)(row0 + k + bs), w.plan, s));
+      LU_TRY(laswp<T>(base + (col0 + k + bs) * ld, ld, tsize, transp, (int)(row0 + k), (int)(row0 + k + bs), w.plan[0], s));
       T* A11 = A + k + k * ld;
       T* A12 = A + k + (k + bs) * ld;
       T* A21 = A + (k + bs) + k * ld;
       T* A22 = A + (k + bs) + (k + bs) * ld;
-      LU_TRY(trsm_unit_lower<T>(A11, A12, ld, bs, tsize, s));        // (:492)
+      if (inverse_applies<T>(bs)) {                                    // (:492)
+        LU_TRY(make_inverse<T>(A11, ld, bs, w.linv[0], s));
+        LU_TRY(apply_inverse<T>(w.linv[0], bs, A12, ld, tsize, s));
+      } else {
+        LU_TRY(trsm_unit_lower<T>(A11, A12, ld, bs, tsize, s));
+      }
       LU_TRY(gemm_minus<T>(trows, tsize, bs, A21, A12, A22, ld, s));  // (:494) the GEMM hot path
     }
   }
@@ -787,27 +889,37 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
     upd = st.update;
   }
   LU_TRY(hipEventRecord(st.ready, upd));  // everything queued before the call
-  for (int64_t k = 0; k < size; k += block) {
+  int step = 0;
+  for (int64_t k = 0; k < size; k += block, ++step) {
     const int64_t bs = std::min(size - k, block);
     const int64_t trows = rows - k - bs, tsize = size - k - bs;
-    LU_TRY(hipStreamWaitEvent(pan, st.ready, 0));
-    LU_TRY(blocked<T>(A, ld, k, k, trows + bs, bs, transp, 16, w, pan));
-    LU_TRY(hipEventRecord(st.factored, pan));
-    LU_TRY(hipStreamWaitEvent(upd, st.factored, 0));
     const int k0 = (int)k, k1 = (int)(k + bs);
     T* A11 = A + k + k * ld;
     T* A21 = A + (k + bs) + k * ld;
+    // Per-step scratch alternates: the panel stream prepares step k+1 while the update stream
+    // still uses what belongs to step k.
+    SwapPlan* plan = w.plan[step & 1];
+    T* linv = w.linv[step & 1];
+    const bool planned = bs > 32 && bs <= kPlanSpan;  // one plan serves the three column ranges of this step
+    const bool inverted = inverse_applies<T>(bs) && trows > 0;
+    LU_TRY(hipStreamWaitEvent(pan, st.ready, 0));
+    LU_TRY(blocked<T>(A, ld, k, k, trows + bs, bs, transp, 16, w, pan));
+    if (planned) LU_TRY(make_plan(transp, k0, k1, plan, pan));
+    if (inverted) LU_TRY(make_inverse<T>(A11, ld, bs, linv, pan));
+    LU_TRY(hipEventRecord(st.factored, pan));
+    LU_TRY(hipStreamWaitEvent(upd, st.factored, 0));
+    auto swap_rows = [&](T* cols, int64_t ncols) {
+      return planned ? apply_plan<T>(cols, ld, ncols, plan, upd) : laswp<T>(cols, ld, ncols, transp, k0, k1, plan, upd);
+    };
+    auto solve = [&](T* A12, int64_t ncols) {
+      return inverted ? apply_inverse<T>(linv, bs, A12, ld, ncols, upd) : trsm_unit_lower<T>(A11, A12, ld, bs, ncols, upd);
+    };
     // columns of the next panel first
     const int64_t nb = trows ? std::min<int64_t>(tsize, block) : 0;
-    const bool planned = bs > 32 && bs <= kPlanSpan;  // one plan serves the three column ranges of this step
-    if (planned) LU_TRY(make_plan(transp, k0, k1, w.plan, upd));
-    auto swap_rows = [&](T* cols, int64_t ncols) {
-      return planned ? apply_plan<T>(cols, ld, ncols, w.plan, upd) : laswp<T>(cols, ld, ncols, transp, k0, k1, w.plan, upd);
-    };
     if (nb > 0) {
       T* A12 = A + k + (k + bs) * ld;
       LU_TRY(swap_rows(A + (k + bs) * ld, nb));
-      LU_TRY(trsm_unit_lower<T>(A11, A12, ld, bs, nb, upd));
+      LU_TRY(solve(A12, nb));
       LU_TRY(gemm_minus<T>(trows, nb, bs, A21, A12, A12 + bs, ld, upd));
     }
     LU_TRY(hipEventRecord(st.ready, upd));
@@ -816,7 +928,7 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
     if (trows && tsize > nb) {
       T* A12 = A + k + (k + bs + nb) * ld;
       LU_TRY(swap_rows(A + (k + bs + nb) * ld, tsize - nb));
-      LU_TRY(trsm_unit_lower<T>(A11, A12, ld, bs, tsize - nb, upd));
+      LU_TRY(solve(A12, tsize - nb));
       LU_TRY(gemm_minus<T>(trows, tsize - nb, bs, A21, A12, A12 + bs, ld, upd));
     }
   }
@@ -905,7 +1017,8 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   const size_t off_side = 64;  // first_zero, nswaps, arrived, exited, error live in the first 64 bytes
   const size_t off_tops = off_side + round64(sizeof(Side<T>));
   const size_t off_plan = off_tops + round64(2 * sizeof(BaseTop<T>));
-  const size_t off_partials = off_plan + round64(sizeof(SwapPlan));
+  const size_t off_linv = off_plan + 2 * round64(sizeof(SwapPlan));
+  const size_t off_partials = off_linv + 2 * round64((size_t)kPlanSpan * kPlanSpan * sizeof(T));
   const size_t off_slots = off_partials + round64(nparts * sizeof(Candidate<T>));
   const size_t nslots = 2 * std::min<size_t>(nparts, kMaxFusedParts);
   const size_t need = off_slots + round64(nslots * sizeof(BaseSlot<T>));
@@ -933,7 +1046,10 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   w.generation = &sc.generation;
   w.side = reinterpret_cast<Side<T>*>(p + off_side);
   w.tops = reinterpret_cast<BaseTop<T>*>(p + off_tops);
-  w.plan = reinterpret_cast<SwapPlan*>(p + off_plan);
+  for (int i = 0; i < 2; ++i) {
+    w.plan[i] = reinterpret_cast<SwapPlan*>(p + off_plan + i * round64(sizeof(SwapPlan)));
+    w.linv[i] = reinterpret_cast<T*>(p + off_linv + i * round64((size_t)kPlanSpan * kPlanSpan * sizeof(T)));
+  }
   w.partials = reinterpret_cast<Candidate<T>*>(p + off_partials);
   w.slots = reinterpret_cast<BaseSlot<T>*>(p + off_slots);
   LU_TRY(hipMemsetAsync(p, 0, 64, s));  // error flag of the fused base case
