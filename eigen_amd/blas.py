@@ -80,3 +80,25 @@ def fill_uniform_host(dtype, rows, cols, seed, ld=None):
     rc = lib.eigamd_fill_uniform_host(KIND_OF_DTYPE[dtype], _ptr(buf), rows, cols, max(ld, 1), seed)
     _lib.check(rc, "eigamd_fill_uniform_host")
     return buf[:rows, :]
+
+
+_F77_TRSM = {_lib.F32: lib.strsm_, _lib.F64: lib.dtrsm_, _lib.C32: lib.ctrsm_, _lib.C64: lib.ztrsm_}
+
+
+def f77_trsm(side, uplo, transa, diag, m, n, alpha, a, lda, b, ldb):
+    """Raw ``?trsm_`` call (blas/level3_impl.h:78-178 in the Eigen tree): op(a) x = alpha b
+    (side 'L') or x op(a) = alpha b (side 'R'), x overwriting ``b``; the kind is taken from
+    ``b.dtype``."""
+    kind = KIND_OF_DTYPE[b.dtype]
+    al = np.array([alpha], dtype=b.dtype)
+    ci = lambda v: ctypes.byref(ctypes.c_int(int(v)))
+    enc = lambda c: c.encode() if isinstance(c, str) else c
+    return _F77_TRSM[kind](enc(side), enc(uplo), enc(transa), enc(diag), ci(m), ci(n), _ptr(al), _ptr(a), ci(lda),
+                           _ptr(b), ci(ldb))
+
+
+def trsm(side, uplo, transa, diag, alpha, a, b):
+    """Solve in place on Fortran-ordered numpy arrays through the F77 entry point."""
+    a, b = _colmajor(a, "a"), _colmajor(b, "b")
+    f77_trsm(side, uplo, transa, diag, b.shape[0], b.shape[1], alpha, a, max(a.shape[0], 1), b, max(b.shape[0], 1))
+    return b

@@ -15,6 +15,7 @@
 #include "../../include/eigen_amd_blas.h"
 #include "gemm_launch.hpp"
 #include "lu.hpp"
+#include "trsm.hpp"
 #include "rng.hpp"
 
 using namespace eigamd;
@@ -408,6 +409,91 @@ int dgetrf_(const int* m, const int* n, double* a, const int* lda, int* ipiv, in
 }
 int sgetrf_(const int* m, const int* n, float* a, const int* lda, int* ipiv, int* info) {
   return f77_getrf(F32, "SGETRF", m, n, a, lda, ipiv, info);
+}
+
+// ---- ?trsm_ (blas/level3_impl.h:78-178) ---------------------------------------------
+
+static int side_of(char c) { return (c == 'L' || c == 'l') ? 0 : (c == 'R' || c == 'r') ? 1 : -1; }   // common.h SIDE
+static int uplo_of(char c) { return (c == 'U' || c == 'u') ? 0 : (c == 'L' || c == 'l') ? 1 : -1; }   // common.h UPLO
+static int diag_of(char c) { return (c == 'N' || c == 'n') ? 0 : (c == 'U' || c == 'u') ? 1 : -1; }   // common.h DIAG
+
+int eigamd_trsm_dev(int dtype, int side, int uplo, int op, int diag, int64_t m, int64_t n, const void* alpha,
+                    const void* d_a, int64_t lda, void* d_b, int64_t ldb, void* stream) {
+  if (dtype < 0 || dtype > 3) return fail(EIGAMD_ERR_ARG, "dtype out of range");
+  if (side < 0 || side > 1 || uplo < 0 || uplo > 1 || op < OP_N || op > OP_C || diag < 0 || diag > 1 || m < 0 || n < 0 ||
+      lda < std::max<int64_t>(1, side == 0 ? m : n) || ldb < std::max<int64_t>(1, m) || m > 0x7fffffff || n > 0x7fffffff)
+    return fail(EIGAMD_ERR_ARG, "invalid trsm arguments");
+  if (m == 0 || n == 0) return EIGAMD_OK;
+  int rc = ensure_device();
+  if (rc != EIGAMD_OK) return rc;
+  double al[2];
+  read_scalar(dtype, alpha, al);
+  HIP_TRY(trsm_device(dtype, side == 0, uplo == 0, op, diag == 1, m, n, al, d_a, lda, d_b, ldb,
+                      static_cast<hipStream_t>(stream)));
+  return EIGAMD_OK;
+}
+
+static int trsm_host_impl(int dtype, int side, int uplo, int op, int diag, int64_t m, int64_t n, const double alpha[2],
+                          const void* a, int64_t lda, void* b, int64_t ldb) {
+  int rc = ensure_device();
+  if (rc != EIGAMD_OK) return rc;
+  const int es = kElemSize[dtype];
+  const int64_t na = side == 0 ? m : n;
+  const int64_t dlda = round_up(na, 16), dldb = round_up(m, 16);
+  Staging& st = staging();
+  std::lock_guard<std::mutex> lock(st.mu);
+  if (!st.stream) HIP_TRY(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
+  if ((rc = st.reserve(0, (size_t)dlda * na * es)) != EIGAMD_OK) return rc;
+  if ((rc = st.reserve(2, (size_t)dldb * n * es)) != EIGAMD_OK) return rc;
+  HIP_TRY(hipMemcpy2DAsync(st.buf[0], dlda * es, a, lda * es, na * es, na, hipMemcpyHostToDevice, st.stream));
+  HIP_TRY(hipMemcpy2DAsync(st.buf[2], dldb * es, b, ldb * es, m * es, n, hipMemcpyHostToDevice, st.stream));
+  HIP_TRY(trsm_device(dtype, side == 0, uplo == 0, op, diag == 1, m, n, alpha, st.buf[0], dlda, st.buf[2], dldb, st.stream));
+  // only the m x n window goes back
+  HIP_TRY(hipMemcpy2DAsync(b, ldb * es, st.buf[2], dldb * es, m * es, n, hipMemcpyDeviceToHost, st.stream));
+  HIP_TRY(hipStreamSynchronize(st.stream));
+  return EIGAMD_OK;
+}
+
+static int f77_trsm(int dtype, const char* name, const char* side, const char* uplo, const char* opa, const char* diag,
+                    const int* m, const int* n, const void* alpha, const void* a, const int* lda, void* b,
+                    const int* ldb) {
+  const int sd = side_of(*side), ul = uplo_of(*uplo), op = op_of(*opa), dg = diag_of(*diag);
+  int info = 0;                                                    // level3_impl.h:146-156
+  if (sd < 0) info = 1;
+  else if (ul < 0) info = 2;
+  else if (op < 0) info = 3;
+  else if (dg < 0) info = 4;
+  else if (*m < 0) info = 5;
+  else if (*n < 0) info = 6;
+  else if (*lda < std::max(1, sd == 0 ? *m : *n)) info = 9;
+  else if (*ldb < std::max(1, *m)) info = 11;
+  if (info) return xerbla_(name, &info, 6);
+  if (*m == 0 || *n == 0) return 0;                                // level3_impl.h:158-159
+  double al[2];
+  read_scalar(dtype, alpha, al);
+  int rc = trsm_host_impl(dtype, sd, ul, op, dg, *m, *n, al, a, *lda, b, *ldb);
+  if (rc != EIGAMD_OK) {
+    std::fprintf(stderr, "eigen_amd %s: %s\n", name, g_err.c_str());
+    std::abort();
+  }
+  return 0;
+}
+
+int strsm_(const char* side, const char* uplo, const char* opa, const char* diag, const int* m, const int* n,
+           const float* alpha, const float* a, const int* lda, float* b, const int* ldb) {
+  return f77_trsm(F32, "STRSM ", side, uplo, opa, diag, m, n, alpha, a, lda, b, ldb);
+}
+int dtrsm_(const char* side, const char* uplo, const char* opa, const char* diag, const int* m, const int* n,
+           const double* alpha, const double* a, const int* lda, double* b, const int* ldb) {
+  return f77_trsm(F64, "DTRSM ", side, uplo, opa, diag, m, n, alpha, a, lda, b, ldb);
+}
+int ctrsm_(const char* side, const char* uplo, const char* opa, const char* diag, const int* m, const int* n,
+           const float* alpha, const float* a, const int* lda, float* b, const int* ldb) {
+  return f77_trsm(C32, "CTRSM ", side, uplo, opa, diag, m, n, alpha, a, lda, b, ldb);
+}
+int ztrsm_(const char* side, const char* uplo, const char* opa, const char* diag, const int* m, const int* n,
+           const double* alpha, const double* a, const int* lda, double* b, const int* ldb) {
+  return f77_trsm(C64, "ZTRSM ", side, uplo, opa, diag, m, n, alpha, a, lda, b, ldb);
 }
 
 const char* eigamd_last_error(void) { return g_err.c_str(); }

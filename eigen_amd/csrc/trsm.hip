@@ -1,0 +1,280 @@
+// Triangular solve with many right-hand sides on the device:
+//   op(A) * X = alpha * B   (side = left)    or    X * op(A) = alpha * B   (side = right),
+// A triangular (upper / lower, unit / non-unit diagonal), X overwrites B.
+//
+// Replaces triangular_solve_matrix (Eigen/src/Core/products/TriangularSolverMatrix.h:40-…)
+// behind EIGEN_BLAS_FUNC(trsm) (blas/level3_impl.h:78-178).  The reference walks small
+// panels with scalar substitution and updates the rest with its GEMM kernel
+// (TriangularSolverMatrix.h:166,183); here the diagonal blocks (128 x 128) are inverted by a
+// small kernel, every block step is ONE in-place product with that inverse, and the update
+// of the remaining blocks is the MFMA GEMM (k = 128).  As in the reference the solve comes
+// first and alpha is applied afterwards (level3_impl.h:163-175).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <mutex>
+
+#include "gemm_launch.hpp"
+#include "trsm.hpp"
+
+namespace eigamd {
+
+namespace {
+
+constexpr int kNB = 128;       // diagonal block
+constexpr int kInvCols = 32;   // columns of the inverse one workgroup owns
+
+// The in-place products below rely on one GEMM tile covering the whole block extent.
+static_assert(Geometry<F32>::BM >= kNB && Geometry<F32>::BN >= kNB, "tile smaller than the trsm block");
+static_assert(Geometry<F64>::BM >= kNB && Geometry<F64>::BN >= kNB, "tile smaller than the trsm block");
+static_assert(Geometry<C32>::BM >= kNB && Geometry<C32>::BN >= kNB, "tile smaller than the trsm block");
+static_assert(Geometry<C64>::BM >= kNB && Geometry<C64>::BN >= kNB, "tile smaller than the trsm block");
+
+template <typename R> struct Cplx {
+  R x, y;
+};
+template <typename R> __device__ __forceinline__ Cplx<R> operator+(Cplx<R> a, Cplx<R> b) { return {a.x + b.x, a.y + b.y}; }
+template <typename R> __device__ __forceinline__ Cplx<R> operator*(Cplx<R> a, Cplx<R> b) {
+  return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+template <typename R> __device__ __forceinline__ Cplx<R> operator-(Cplx<R> a) { return {-a.x, -a.y}; }
+// Smith's division, as std::complex does it.
+template <typename R> __device__ __forceinline__ Cplx<R> operator/(Cplx<R> a, Cplx<R> b) {
+  if (fabs(b.x) >= fabs(b.y)) {
+    const R r = b.y / b.x, d = b.x + b.y * r;
+    return {(a.x + a.y * r) / d, (a.y - a.x * r) / d};
+  }
+  const R r = b.x / b.y, d = b.x * r + b.y;
+  return {(a.x * r + a.y) / d, (a.y * r - a.x) / d};
+}
+template <typename T> __device__ __forceinline__ T zero_of() { return T{}; }
+template <typename T> struct One;
+template <> struct One<float> { static __device__ float v() { return 1.f; } };
+template <> struct One<double> { static __device__ double v() { return 1.0; } };
+template <> struct One<Cplx<float>> { static __device__ Cplx<float> v() { return {1.f, 0.f}; } };
+template <> struct One<Cplx<double>> { static __device__ Cplx<double> v() { return {1.0, 0.0}; } };
+
+// Inverse of every diagonal block of the na x na triangular matrix A at once.  Block b
+// (rows/columns [b*kNB, b*kNB + nbb)) is read through its stored triangle only -- the other
+// triangle, and the diagonal when `unit`, are never touched (the Netlib testers fill them
+// with rogue values) -- and its inverse is written as a full kNB x kNB matrix (zeros in the
+// other triangle) at X + b * kNB * kNB.  An upper triangle is inverted as the transpose of
+// a lower one.  grid = (kNB / kInvCols, number of blocks); a workgroup owns 32 columns of
+// one inverse in LDS and walks down the rows 32 at a time: first the part of the inner
+// products that needs finished rows only, then the 32 x 32 triangle on the diagonal.
+template <typename T>
+__global__ void __launch_bounds__(256) trtri_blocks(const T* __restrict__ A, int64_t lda, int na, int upper, int unit,
+                                                    T* __restrict__ X) {
+  __shared__ T s_x[kInvCols][kNB + 1];
+  __shared__ T s_acc[kInvCols][kInvCols + 1];
+  __shared__ T s_d[kInvCols][kInvCols + 1];  // s_d[k - i0][i - i0] = L(i, k) of the diagonal 32 x 32
+  __shared__ T s_diag[kInvCols];             // L(i, i) of those rows
+  const int b0 = blockIdx.y * kNB;
+  const int bs = min(kNB, na - b0);
+  const T* Ab = A + b0 + (int64_t)b0 * lda;
+  T* Xb = X + (int64_t)blockIdx.y * kNB * kNB;
+  auto at = [&](int i, int k) { return upper ? Ab[k + (int64_t)i * lda] : Ab[i + (int64_t)k * lda]; };  // i > k
+  const int first = blockIdx.x * kInvCols;
+  for (int idx = threadIdx.x; idx < kInvCols * kNB; idx += 256) s_x[idx / kNB][idx % kNB] = zero_of<T>();
+  __syncthreads();
+  const int il = threadIdx.x % kInvCols, cg = threadIdx.x / kInvCols;
+  for (int i0 = first; i0 < bs; i0 += kInvCols) {
+    const int i = i0 + il;
+    T acc[4] = {zero_of<T>(), zero_of<T>(), zero_of<T>(), zero_of<T>()};
+    if (i < bs) {
+      for (int k = first; k < i0; k += 8) {
+        T l[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) l[u] = at(i, k + u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] = acc[q] + l[u] * s_x[cg * 4 + q][k + u];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s_acc[cg * 4 + q][il] = acc[q];
+    for (int idx = threadIdx.x; idx < kInvCols * kInvCols; idx += 256) {
+      const int kk = idx / kInvCols, ii = idx % kInvCols;
+      s_d[kk][ii] = (i0 + ii < bs && ii > kk) ? at(i0 + ii, i0 + kk) : zero_of<T>();
+    }
+    if (threadIdx.x < kInvCols) {
+      const int r = i0 + threadIdx.x;
+      s_diag[threadIdx.x] = (unit || r >= bs) ? One<T>::v() : Ab[r + (int64_t)r * lda];
+    }
+    __syncthreads();
+    if (threadIdx.x < kInvCols) {
+      const int c = threadIdx.x, g = first + c;
+      T x[kInvCols];
+#pragma unroll
+      for (int ii = 0; ii < kInvCols; ++ii) {
+        T v = s_acc[c][ii];
+#pragma unroll
+        for (int kk = 0; kk < kInvCols; ++kk)
+          if (kk < ii) v = v + s_d[kk][ii] * x[kk];
+        const int row = i0 + ii;
+        if (g >= bs || row >= bs || row < g) x[ii] = zero_of<T>();
+        else if (row == g) x[ii] = One<T>::v() / s_diag[ii];
+        else x[ii] = -(v / s_diag[ii]);
+      }
+#pragma unroll
+      for (int ii = 0; ii < kInvCols; ++ii)
+        if (i0 + ii < bs) s_x[c][i0 + ii] = x[ii];
+    }
+    __syncthreads();
+  }
+  // full kNB x kNB image, zeros outside the bs x bs triangle
+  for (int idx = threadIdx.x; idx < kInvCols * kNB; idx += 256) {
+    const int c = idx / kNB, i = idx % kNB;
+    const int g = first + c;
+    const T v = (g < bs && i < bs) ? s_x[c][i] : zero_of<T>();
+    if (upper) Xb[g + (int64_t)i * kNB] = v;
+    else Xb[i + (int64_t)g * kNB] = v;
+  }
+}
+
+hipError_t gemm(int kind, int opa, int opb, int64_t m, int64_t n, int64_t k, double alpha, const void* A, int64_t lda,
+                const void* B, int64_t ldb, double beta, void* C, int64_t ldc, hipStream_t s) {
+  if (m <= 0 || n <= 0) return hipSuccess;
+  GemmCall c;
+  c.kind = kind;
+  c.opa = opa; c.opb = opb;
+  c.m = m; c.n = n; c.k = k;
+  c.alpha[0] = alpha; c.alpha[1] = 0.0;
+  c.beta[0] = beta; c.beta[1] = 0.0;
+  c.A = A; c.lda = lda;
+  c.B = B; c.ldb = ldb;
+  c.C = C; c.ldc = ldc;
+  switch (kind) {
+    case F32: return launch_gemm_f32(c, s);
+    case F64: return launch_gemm_f64(c, s);
+    case C32: return launch_gemm_c32(c, s);
+    default:  return launch_gemm_c64(c, s);
+  }
+}
+
+constexpr int kElem[4] = {4, 8, 8, 16};
+
+struct InvScratch {
+  std::mutex mu;
+  void* buf = nullptr;
+  size_t cap = 0;
+  hipEvent_t done = nullptr;  // last use of buf
+};
+InvScratch& inv_scratch() {
+  static InvScratch s;
+  return s;
+}
+
+#define TR_TRY(expr)                 \
+  do {                               \
+    hipError_t e_ = (expr);          \
+    if (e_ != hipSuccess) return e_; \
+  } while (0)
+
+}  // namespace
+
+hipError_t trsm_device(int kind, bool left, bool upper, int op, bool unit, int64_t m, int64_t n, const double alpha[2],
+                       const void* A, int64_t lda, void* B, int64_t ldb, hipStream_t s) {
+  if (m <= 0 || n <= 0) return hipSuccess;
+  const int es = kElem[kind];
+  const int64_t na = left ? m : n;
+  const int64_t nblk = (na + kNB - 1) / kNB;
+  const char* Ab = static_cast<const char*>(A);
+  char* Bb = static_cast<char*>(B);
+  auto a_at = [&](int64_t r, int64_t c) { return Ab + (r + c * lda) * es; };
+  auto b_at = [&](int64_t r, int64_t c) { return Bb + (r + c * ldb) * es; };
+
+  // inverses of all diagonal blocks (scratch shared by all callers: a use waits for the last one)
+  InvScratch& sc = inv_scratch();
+  std::lock_guard<std::mutex> lock(sc.mu);
+  const size_t need = (size_t)nblk * kNB * kNB * es;
+  if (!sc.done) TR_TRY(hipEventCreateWithFlags(&sc.done, hipEventDisableTiming));
+  if (need > sc.cap) {
+    if (sc.buf) {
+      TR_TRY(hipEventSynchronize(sc.done));
+      TR_TRY(hipFree(sc.buf));
+      sc.buf = nullptr;
+      sc.cap = 0;
+    }
+    TR_TRY(hipMalloc(&sc.buf, need + need / 4));
+    sc.cap = need + need / 4;
+  } else {
+    TR_TRY(hipStreamWaitEvent(s, sc.done, 0));
+  }
+  const dim3 grid(kNB / kInvCols, (unsigned)nblk);
+  switch (kind) {
+    case F32:
+      hipLaunchKernelGGL(trtri_blocks<float>, grid, dim3(256), 0, s, static_cast<const float*>(A), lda, (int)na, upper ? 1 : 0,
+                         unit ? 1 : 0, static_cast<float*>(sc.buf));
+      break;
+    case F64:
+      hipLaunchKernelGGL(trtri_blocks<double>, grid, dim3(256), 0, s, static_cast<const double*>(A), lda, (int)na,
+                         upper ? 1 : 0, unit ? 1 : 0, static_cast<double*>(sc.buf));
+      break;
+    case C32:
+      hipLaunchKernelGGL(trtri_blocks<Cplx<float>>, grid, dim3(256), 0, s, static_cast<const Cplx<float>*>(A), lda, (int)na,
+                         upper ? 1 : 0, unit ? 1 : 0, static_cast<Cplx<float>*>(sc.buf));
+      break;
+    default:
+      hipLaunchKernelGGL(trtri_blocks<Cplx<double>>, grid, dim3(256), 0, s, static_cast<const Cplx<double>*>(A), lda,
+                         (int)na, upper ? 1 : 0, unit ? 1 : 0, static_cast<Cplx<double>*>(sc.buf));
+      break;
+  }
+  TR_TRY(hipGetLastError());
+  auto inv = [&](int64_t j) { return static_cast<const char*>(sc.buf) + (size_t)j * kNB * kNB * es; };
+
+  const bool notrans = op == OP_N;
+  const bool eff_lower = (!upper) == notrans;  // op(A) is lower triangular
+  if (left) {
+    // forward over row blocks when op(A) is lower, backward when it is upper
+    for (int64_t t = 0; t < nblk; ++t) {
+      const int64_t j = eff_lower ? t : nblk - 1 - t;
+      const int64_t r0 = j * kNB, rb = std::min<int64_t>(kNB, m - r0);
+      // B_j <- op(inv_j) * B_j, in place (one tile row)
+      TR_TRY(gemm(kind, op, OP_N, rb, n, rb, 1.0, inv(j), kNB, b_at(r0, 0), ldb, 0.0, b_at(r0, 0), ldb, s));
+      const int64_t q0 = eff_lower ? r0 + rb : 0, qn = eff_lower ? m - q0 : r0;  // rows still to solve
+      if (qn > 0) {
+        // B_q -= op(A)(q, j) * B_j
+        const void* Aqj = notrans ? a_at(q0, r0) : a_at(r0, q0);
+        TR_TRY(gemm(kind, op, OP_N, qn, n, rb, -1.0, Aqj, lda, b_at(r0, 0), ldb, 1.0, b_at(q0, 0), ldb, s));
+      }
+    }
+  } else {
+    // X * op(A) = B: forward over column blocks when op(A) is upper, backward when lower
+    for (int64_t t = 0; t < nblk; ++t) {
+      const int64_t j = eff_lower ? nblk - 1 - t : t;
+      const int64_t c0 = j * kNB, cb = std::min<int64_t>(kNB, n - c0);
+      // B_j <- B_j * op(inv_j), in place (one tile column)
+      TR_TRY(gemm(kind, OP_N, op, m, cb, cb, 1.0, b_at(0, c0), ldb, inv(j), kNB, 0.0, b_at(0, c0), ldb, s));
+      const int64_t q0 = eff_lower ? 0 : c0 + cb, qn = eff_lower ? c0 : n - q0;  // columns still to solve
+      if (qn > 0) {
+        // B_q -= B_j * op(A)(j, q)
+        const void* Ajq = notrans ? a_at(c0, q0) : a_at(q0, c0);
+        TR_TRY(gemm(kind, OP_N, op, m, qn, cb, -1.0, b_at(0, c0), ldb, Ajq, lda, 1.0, b_at(0, q0), ldb, s));
+      }
+    }
+  }
+  TR_TRY(hipEventRecord(sc.done, s));
+  if (!(alpha[0] == 1.0 && alpha[1] == 0.0)) {  // B *= alpha (level3_impl.h:174-175)
+    GemmCall c;
+    c.kind = kind;
+    c.opa = OP_N; c.opb = OP_N;
+    c.m = m; c.n = n; c.k = 0;
+    c.alpha[0] = 0.0; c.alpha[1] = 0.0;
+    c.beta[0] = alpha[0]; c.beta[1] = alpha[1];
+    c.A = nullptr; c.lda = 1;
+    c.B = nullptr; c.ldb = 1;
+    c.C = B; c.ldc = ldb;
+    switch (kind) {
+      case F32: TR_TRY(launch_gemm_f32(c, s)); break;
+      case F64: TR_TRY(launch_gemm_f64(c, s)); break;
+      case C32: TR_TRY(launch_gemm_c32(c, s)); break;
+      default:  TR_TRY(launch_gemm_c64(c, s)); break;
+    }
+  }
+  return hipSuccess;
+}
+
+}  // namespace eigamd

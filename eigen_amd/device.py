@@ -86,3 +86,16 @@ def gemm_dev(opa, opb, alpha, a, b, beta, c, stream=None):
                              c.ld, _stream_ptr(stream))
     _lib.check(rc, "eigamd_gemm_dev")
     return c
+
+
+def trsm_dev(side, uplo, transa, diag, alpha, a, b, stream=None):
+    """op(a) x = alpha b (side 'L') or x op(a) = alpha b (side 'R') on DeviceMatrix operands,
+    x overwriting b; asynchronous on ``stream`` (``eigamd_trsm_dev``)."""
+    if a.kind != b.kind:
+        raise ValueError("operands must share one scalar kind")
+    al = np.array([alpha], dtype=_NP_OF_KIND[b.kind])
+    rc = lib.eigamd_trsm_dev(b.kind, "LR".index(side.upper()), "UL".index(uplo.upper()), _OPCODE[transa.upper()],
+                             "NU".index(diag.upper()), b.rows, b.cols, ctypes.c_void_p(al.ctypes.data),
+                             ctypes.c_void_p(a.ptr), a.ld, ctypes.c_void_p(b.ptr), b.ld, _stream_ptr(stream))
+    _lib.check(rc, "eigamd_trsm_dev")
+    return b

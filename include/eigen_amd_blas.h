@@ -120,6 +120,35 @@ int eigamd_laswp_dev(int dtype, void* d_a, int64_t lda, int64_t ncols, const int
 int eigamd_trsm_llnu_dev(int dtype, int64_t m, int64_t n, const void* d_l, int64_t ldl, void* d_b, int64_t ldb,
                          void* stream);
 
+/* ---- triangular solve with many right-hand sides -------------------------------
+ *
+ * strsm_/dtrsm_/ctrsm_/ztrsm_ replace EIGEN_BLAS_FUNC(trsm) (blas/level3_impl.h:78-178;
+ * prototypes Eigen/src/misc/blas.h): op(A) X = alpha B (side 'L') or X op(A) = alpha B
+ * (side 'R'), X overwriting the m x n matrix B; A triangular, only the uplo triangle is
+ * read and not the diagonal when diag = 'U'.  Same checks and xerbla_ codes (1 side,
+ * 2 uplo, 3 transa, 4 diag, 5 m, 6 n, 9 lda, 11 ldb), same quick return for m == 0 or
+ * n == 0; as in the reference the solve comes first and alpha is applied to the result.
+ * They are what Eigen's TriangularSolverMatrix_BLAS.h:43-101 binds under EIGEN_USE_BLAS.
+ *
+ * eigamd_trsm_dev: the same on matrices already in HBM, 64-bit extents, asynchronous on
+ * `stream`. */
+#define EIGAMD_SIDE_LEFT 0
+#define EIGAMD_SIDE_RIGHT 1
+#define EIGAMD_UPLO_UPPER 0
+#define EIGAMD_UPLO_LOWER 1
+#define EIGAMD_DIAG_NONUNIT 0
+#define EIGAMD_DIAG_UNIT 1
+int strsm_(const char* side, const char* uplo, const char* transa, const char* diag, const int* m, const int* n,
+           const float* alpha, const float* a, const int* lda, float* b, const int* ldb);
+int dtrsm_(const char* side, const char* uplo, const char* transa, const char* diag, const int* m, const int* n,
+           const double* alpha, const double* a, const int* lda, double* b, const int* ldb);
+int ctrsm_(const char* side, const char* uplo, const char* transa, const char* diag, const int* m, const int* n,
+           const float* alpha, const float* a, const int* lda, float* b, const int* ldb);
+int ztrsm_(const char* side, const char* uplo, const char* transa, const char* diag, const int* m, const int* n,
+           const double* alpha, const double* a, const int* lda, double* b, const int* ldb);
+int eigamd_trsm_dev(int dtype, int side, int uplo, int op, int diag, int64_t m, int64_t n, const void* alpha,
+                    const void* d_a, int64_t lda, void* d_b, int64_t ldb, void* stream);
+
 /* ---- misc --------------------------------------------------------------------- */
 const char* eigamd_last_error(void);  /* text of the last failure on this thread */
 int eigamd_device_ok(void);           /* 1 if a gfx950 device is usable, else 0 */

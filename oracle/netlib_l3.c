@@ -1,9 +1,9 @@
-/* Restatement in C of the GEMM part of the Netlib level-3 BLAS testers that the
+/* Restatement in C of the GEMM and TRSM parts of the Netlib level-3 BLAS testers that the
  * reference ships as Fortran (blas/testing/{s,d,c,z}blat3.f; no Fortran compiler
  * exists in this image): the deterministic generators ?BEG, ?MAKE('GE'), the
- * result checker ?MMCH, the driver ?CHK1 and the GEMM rows of the error-exit
- * table ?CHKE.  The routine under test is passed in as a function pointer with
- * the F77 ?gemm_ signature.
+ * result checker ?MMCH, the drivers ?CHK1 (GEMM) and ?CHK3 (TRSM rows, with ?MAKE('TR'))
+ * and the GEMM and TRSM rows of the error-exit table ?CHKE.  The routine under test is
+ * passed in as a function pointer with the F77 ?gemm_ / ?trsm_ signature.
  *
  * TEST INFRASTRUCTURE ONLY (see gemm_oracle.c).
  */
@@ -17,6 +17,9 @@
 typedef int (*gemm_fn_t)(const char *, const char *, const int *, const int *, const int *, const void *,
                          const void *, const int *, const void *, const int *, const void *, void *,
                          const int *);
+
+typedef int (*trsm_fn_t)(const char *, const char *, const char *, const char *, const int *, const int *, const void *,
+                         const void *, const int *, void *, const int *);
 
 struct netlib_report {
   int ncalls;        /* calls made by ?CHK1 */
@@ -136,6 +139,46 @@ int netlib_chke_gemm(gemm_fn_t gemm, char letter) {
     netlib_xerbla_info = 0;
     gemm(&rows[r].ta, &rows[r].tb, &rows[r].m, &rows[r].n, &rows[r].k, single ? (void *)alphaf : (void *)alpha, a,
          &rows[r].lda, b, &rows[r].ldb, single ? (void *)betaf : (void *)beta, c, &rows[r].ldc);
+    if (netlib_xerbla_count != 1 || netlib_xerbla_info != rows[r].infot || strncmp(netlib_xerbla_name, want, 6) != 0)
+      nfail += 1;
+  }
+  netlib_xerbla_count = 0;
+  return nfail;
+}
+
+/* TRSM rows of ?CHKE (dblat3.f:2150-2260): as above, 36 calls. */
+int netlib_chke_trsm(trsm_fn_t trsm, char letter) {
+  static const struct { int infot; char sd, ul, tr, dg; int m, n, lda, ldb; } rows[] = {
+      {1, '/', 'U', 'N', 'N', 0, 0, 1, 1},  {2, 'L', '/', 'N', 'N', 0, 0, 1, 1},
+      {3, 'L', 'U', '/', 'N', 0, 0, 1, 1},  {4, 'L', 'U', 'N', '/', 0, 0, 1, 1},
+      {5, 'L', 'U', 'N', 'N', -1, 0, 1, 1}, {5, 'L', 'U', 'T', 'N', -1, 0, 1, 1},
+      {5, 'R', 'U', 'N', 'N', -1, 0, 1, 1}, {5, 'R', 'U', 'T', 'N', -1, 0, 1, 1},
+      {5, 'L', 'L', 'N', 'N', -1, 0, 1, 1}, {5, 'L', 'L', 'T', 'N', -1, 0, 1, 1},
+      {5, 'R', 'L', 'N', 'N', -1, 0, 1, 1}, {5, 'R', 'L', 'T', 'N', -1, 0, 1, 1},
+      {6, 'L', 'U', 'N', 'N', 0, -1, 1, 1}, {6, 'L', 'U', 'T', 'N', 0, -1, 1, 1},
+      {6, 'R', 'U', 'N', 'N', 0, -1, 1, 1}, {6, 'R', 'U', 'T', 'N', 0, -1, 1, 1},
+      {6, 'L', 'L', 'N', 'N', 0, -1, 1, 1}, {6, 'L', 'L', 'T', 'N', 0, -1, 1, 1},
+      {6, 'R', 'L', 'N', 'N', 0, -1, 1, 1}, {6, 'R', 'L', 'T', 'N', 0, -1, 1, 1},
+      {9, 'L', 'U', 'N', 'N', 2, 0, 1, 2},  {9, 'L', 'U', 'T', 'N', 2, 0, 1, 2},
+      {9, 'R', 'U', 'N', 'N', 0, 2, 1, 1},  {9, 'R', 'U', 'T', 'N', 0, 2, 1, 1},
+      {9, 'L', 'L', 'N', 'N', 2, 0, 1, 2},  {9, 'L', 'L', 'T', 'N', 2, 0, 1, 2},
+      {9, 'R', 'L', 'N', 'N', 0, 2, 1, 1},  {9, 'R', 'L', 'T', 'N', 0, 2, 1, 1},
+      {11, 'L', 'U', 'N', 'N', 2, 0, 2, 1}, {11, 'L', 'U', 'T', 'N', 2, 0, 2, 1},
+      {11, 'R', 'U', 'N', 'N', 2, 0, 1, 1}, {11, 'R', 'U', 'T', 'N', 2, 0, 1, 1},
+      {11, 'L', 'L', 'N', 'N', 2, 0, 2, 1}, {11, 'L', 'L', 'T', 'N', 2, 0, 2, 1},
+      {11, 'R', 'L', 'N', 'N', 2, 0, 1, 1}, {11, 'R', 'L', 'T', 'N', 2, 0, 1, 1},
+  };
+  double a[8] = {0}, b[8] = {0}, alpha[2] = {1, 0};
+  float alphaf[2] = {1, 0};
+  const int single = letter == 'S' || letter == 'C';
+  char want[8];
+  snprintf(want, sizeof want, "%cTRSM ", letter);
+  int nfail = 0;
+  for (unsigned r = 0; r < sizeof rows / sizeof rows[0]; ++r) {
+    netlib_xerbla_count = 0;
+    netlib_xerbla_info = 0;
+    trsm(&rows[r].sd, &rows[r].ul, &rows[r].tr, &rows[r].dg, &rows[r].m, &rows[r].n, single ? (void *)alphaf : (void *)alpha,
+         a, &rows[r].lda, b, &rows[r].ldb);
     if (netlib_xerbla_count != 1 || netlib_xerbla_info != rows[r].infot || strncmp(netlib_xerbla_name, want, 6) != 0)
       nfail += 1;
   }

@@ -158,6 +158,83 @@ def run_netlib_chke(kind, gemm_fn):
     return oracle.netlib_chke_gemm(ctypes.cast(gemm_fn, ctypes.c_void_p), ctypes.c_char("SDCZ"[kind].encode()))
 
 
+def run_netlib_chk3_trsm(kind, trsm_fn, params):
+    """Restated TRSM rows of ?CHK3 over `trsm_fn` (a ctypes function with the ?trsm_ signature)."""
+    real = ctypes.c_float if kind in (0, 2) else ctypes.c_double
+    idim = (ctypes.c_int * len(params["idim"]))(*params["idim"])
+    alf = (real * len(params["alf"]))(*params["alf"])
+    per = 2 if params["cplx"] else 1
+    rep = NetlibReport()
+    f = getattr(oracle, "netlib_chk3_trsm_" + SUFFIX[kind])
+    f(ctypes.cast(trsm_fn, ctypes.c_void_p), len(params["idim"]), idim, len(params["alf"]) // per, alf, ctypes.byref(rep))
+    return rep
+
+
+def run_netlib_chke_trsm(kind, trsm_fn):
+    return oracle.netlib_chke_trsm(ctypes.cast(trsm_fn, ctypes.c_void_p), ctypes.c_char("SDCZ"[kind].encode()))
+
+
+def oracle_trsm(kind):
+    return getattr(oracle, "oracle_trsm_" + SUFFIX[kind])
+
+
+def call_f77_trsm(fn, side, uplo, transa, diag, m, n, alpha, a, lda, b, ldb):
+    """Call any function with the F77 ?trsm_ signature on numpy buffers (b is overwritten)."""
+    al = np.array([alpha], dtype=b.dtype)
+    ci = lambda v: ctypes.byref(ctypes.c_int(int(v)))
+    cs = lambda c: ctypes.c_char_p(c.encode())
+    fn(cs(side), cs(uplo), cs(transa), cs(diag), ci(m), ci(n), _vp(al), _vp(a), ci(lda), _vp(b), ci(ldb))
+    return b
+
+
+def trsm_operands(kind, side, uplo, diag, m, n, seed, pad=0, rogue=True):
+    """A well-conditioned triangular A (m x m or n x n) and a general B (m x n), column-major
+    with `pad` extra rows, from the library's counter-based generator.  Off-diagonal entries
+    are U[-1,1) * 2/na, the diagonal 1.5 + 0.5 * U[-1,1); the triangle that ?trsm_ must not read
+    (and the diagonal when diag = 'U') holds -1e10 when `rogue`."""
+    import eigen_amd
+    dt = DTYPES[kind]
+    na = m if side == "L" else n
+    a = eigen_amd.fill_uniform_host(dt, na, na, seed, ld=na + pad)
+    b = eigen_amd.fill_uniform_host(dt, m, n, seed + 1, ld=m + pad)
+    if na:
+        i, j = np.indices((na, na))
+        d = np.diagonal(a).copy()
+        a *= 2.0 / na
+        a[i == j] = 1.5 + 0.5 * d
+        hide = (i > j) if uplo == "U" else (i < j)
+        if diag == "U":
+            hide = hide | (i == j)
+        if rogue:
+            a[hide] = -1.0e10
+    return a, b
+
+
+def dense_op_triangle(a, uplo, transa, diag):
+    """op(A) as a dense matrix: the stored triangle, unit diagonal if asked, transposed /
+    conjugated as `transa` says."""
+    t = np.triu(a) if uplo == "U" else np.tril(a)
+    if diag == "U":
+        t = t - np.diag(np.diagonal(t)) + np.eye(a.shape[0], dtype=a.dtype)
+    if transa == "T":
+        t = t.T
+    elif transa == "C":
+        t = t.conj().T
+    return t
+
+
+def trsm_residual_ratio(kind, side, uplo, transa, diag, alpha, a, b0, x):
+    """?MMCH-style componentwise ratio of op(A) X (or X op(A)) against alpha B:
+    |op(A) X - alpha B| / (eps * (|op(A)| |X| + |alpha| |B|))."""
+    abs1 = (lambda z: np.abs(z.real) + np.abs(z.imag)) if np.iscomplexobj(x) else np.abs
+    t = dense_op_triangle(np.asarray(a), uplo, transa, diag).astype(np.complex128 if kind >= 2 else np.float64)
+    xx, bb = x.astype(t.dtype), b0.astype(t.dtype)
+    r = (t @ xx if side == "L" else xx @ t) - alpha * bb
+    g = (abs1(t) @ abs1(xx) if side == "L" else abs1(xx) @ abs1(t)) + abs1(np.asarray(alpha)) * abs1(bb)
+    g = np.where(g == 0, 1.0, g)
+    return float((abs1(r) / (EPS[kind] * g)).max()) if x.size else 0.0
+
+
 def gauge_ratio(kind, got, ref, alpha, a_abs1, b_abs1, beta, c0, k):
     """Componentwise ?MMCH-style ratio |got - ref| / (eps * G) with
     G = abs1(alpha) * (|A| |B|)_ij + abs1(beta) * abs1(c0_ij)."""
