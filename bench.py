@@ -155,6 +155,28 @@ def side_measurement(dtype, n, steps):
     return round(flops / best / 1e9, 2)
 
 
+def trsm_measurement(n):
+    """dtrsm('L','L','N','N') with an n x n triangle and n right-hand sides resident in HBM
+    (eigamd_trsm_dev); n^3 flop.  The block updates run on the GEMM kernel."""
+    import torch
+    import eigen_amd
+    from eigen_amd.device import DeviceMatrix, trsm_dev
+    a = DeviceMatrix(n, n, eigen_amd.F64).fill_uniform(5)
+    a.as_strided().mul_(2.0 / n)
+    a.as_strided().diagonal().fill_(1.5)
+    b = DeviceMatrix(n, n, eigen_amd.F64)
+    best = 1e30
+    for _ in range(3):
+        b.fill_uniform(6)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        trsm_dev("L", "L", "N", "N", 1.0, a, b)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return {f"dtrsm_llnn_{n}_tflops": round(float(n) ** 3 / best / 1e9, 2)}
+
+
 def lu_measurement(n):
     """PartialPivLU-equivalent factorisation (eigamd_getrf_dev) of an n x n double matrix
     resident in HBM; 2/3 n^3 flop.  The trailing updates run on the GEMM kernel."""
@@ -339,6 +361,7 @@ def main():
                     "cgemm_8192_tflops": side_measurement("c32", 8192, 3),
                 }
                 out["extra"].update(lu_measurement(32768))
+                out["extra"].update(trsm_measurement(16384))
                 out["extra"]["sgemm_pct_of_peak"] = round(100 * out["extra"]["sgemm_16384_tflops"] / PEAK_TFLOPS["f32"], 2)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args)

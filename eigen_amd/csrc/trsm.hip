@@ -6,13 +6,14 @@
 // behind EIGEN_BLAS_FUNC(trsm) (blas/level3_impl.h:78-178).  The reference walks small
 // panels with scalar substitution and updates the rest with its GEMM kernel
 // (TriangularSolverMatrix.h:166,183); here the diagonal blocks (128 x 128) are inverted by a
-// small kernel, every block step is ONE in-place product with that inverse, and the update
-// of the remaining blocks is the MFMA GEMM (k = 128).  As in the reference the solve comes
-// first and alpha is applied afterwards (level3_impl.h:163-175).
+// small kernel, a block solve is ONE in-place product with that inverse, and the blocks are
+// combined by recursive halving, whose updates are MFMA GEMMs with long reductions.  As in
+// the reference the solve comes first and alpha is applied afterwards (level3_impl.h:163-175).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cstdint>
+#include <functional>
 #include <mutex>
 
 #include "gemm_launch.hpp"
@@ -227,35 +228,43 @@ hipError_t trsm_device(int kind, bool left, bool upper, int op, bool unit, int64
 
   const bool notrans = op == OP_N;
   const bool eff_lower = (!upper) == notrans;  // op(A) is lower triangular
-  if (left) {
-    // forward over row blocks when op(A) is lower, backward when it is upper
-    for (int64_t t = 0; t < nblk; ++t) {
-      const int64_t j = eff_lower ? t : nblk - 1 - t;
-      const int64_t r0 = j * kNB, rb = std::min<int64_t>(kNB, m - r0);
-      // B_j <- op(inv_j) * B_j, in place (one tile row)
-      TR_TRY(gemm(kind, op, OP_N, rb, n, rb, 1.0, inv(j), kNB, b_at(r0, 0), ldb, 0.0, b_at(r0, 0), ldb, s));
-      const int64_t q0 = eff_lower ? r0 + rb : 0, qn = eff_lower ? m - q0 : r0;  // rows still to solve
-      if (qn > 0) {
-        // B_q -= op(A)(q, j) * B_j
-        const void* Aqj = notrans ? a_at(q0, r0) : a_at(r0, q0);
-        TR_TRY(gemm(kind, op, OP_N, qn, n, rb, -1.0, Aqj, lda, b_at(r0, 0), ldb, 1.0, b_at(q0, 0), ldb, s));
-      }
-    }
-  } else {
-    // X * op(A) = B: forward over column blocks when op(A) is upper, backward when lower
-    for (int64_t t = 0; t < nblk; ++t) {
-      const int64_t j = eff_lower ? nblk - 1 - t : t;
-      const int64_t c0 = j * kNB, cb = std::min<int64_t>(kNB, n - c0);
+  // Recursive halving over the diagonal blocks [j0, j1): solve the half that does not depend
+  // on the other, update the other half with ONE product whose reduction length is the size
+  // of the first half (so the large updates run at GEMM speed and B is re-read O(log) times),
+  // solve the other half.  Left: blocks are row blocks of B, forward when op(A) is lower.
+  // Right (X op(A) = B): blocks are column blocks of B, forward when op(A) is upper.
+  struct Rec {
+    std::function<hipError_t(int64_t, int64_t)> run;
+  } rec;
+  const int64_t ext = na;
+  rec.run = [&](int64_t j0, int64_t j1) -> hipError_t {
+    if (j1 - j0 == 1) {
+      const int64_t p0 = j0 * kNB, pb = std::min<int64_t>(kNB, ext - p0);
+      if (left)  // B_j <- op(inv_j) * B_j, in place (one tile row)
+        return gemm(kind, op, OP_N, pb, n, pb, 1.0, inv(j0), kNB, b_at(p0, 0), ldb, 0.0, b_at(p0, 0), ldb, s);
       // B_j <- B_j * op(inv_j), in place (one tile column)
-      TR_TRY(gemm(kind, OP_N, op, m, cb, cb, 1.0, b_at(0, c0), ldb, inv(j), kNB, 0.0, b_at(0, c0), ldb, s));
-      const int64_t q0 = eff_lower ? 0 : c0 + cb, qn = eff_lower ? c0 : n - q0;  // columns still to solve
-      if (qn > 0) {
-        // B_q -= B_j * op(A)(j, q)
-        const void* Ajq = notrans ? a_at(c0, q0) : a_at(q0, c0);
-        TR_TRY(gemm(kind, OP_N, op, m, qn, cb, -1.0, b_at(0, c0), ldb, Ajq, lda, 1.0, b_at(0, q0), ldb, s));
-      }
+      return gemm(kind, OP_N, op, m, pb, pb, 1.0, b_at(0, p0), ldb, inv(j0), kNB, 0.0, b_at(0, p0), ldb, s);
     }
-  }
+    const int64_t jm = j0 + (j1 - j0 + 1) / 2;
+    const int64_t lo0 = j0 * kNB, lo1 = jm * kNB, hi1 = std::min<int64_t>(j1 * kNB, ext);
+    const int64_t nlo = lo1 - lo0, nhi = hi1 - lo1;
+    const bool low_first = left ? eff_lower : !eff_lower;   // which half is solved first
+    TR_TRY(low_first ? rec.run(j0, jm) : rec.run(jm, j1));
+    // f = the finished half, q = the half still to solve
+    const int64_t f0 = low_first ? lo0 : lo1, fn = low_first ? nlo : nhi;
+    const int64_t q0 = low_first ? lo1 : lo0, qn = low_first ? nhi : nlo;
+    if (left) {
+      // B_q -= op(A)(q, f) * B_f
+      const void* Aqf = notrans ? a_at(q0, f0) : a_at(f0, q0);
+      TR_TRY(gemm(kind, op, OP_N, qn, n, fn, -1.0, Aqf, lda, b_at(f0, 0), ldb, 1.0, b_at(q0, 0), ldb, s));
+    } else {
+      // B_q -= B_f * op(A)(f, q)
+      const void* Afq = notrans ? a_at(f0, q0) : a_at(q0, f0);
+      TR_TRY(gemm(kind, OP_N, op, m, qn, fn, -1.0, b_at(0, f0), ldb, Afq, lda, 1.0, b_at(0, q0), ldb, s));
+    }
+    return low_first ? rec.run(jm, j1) : rec.run(j0, jm);
+  };
+  TR_TRY(rec.run(0, nblk));
   TR_TRY(hipEventRecord(sc.done, s));
   if (!(alpha[0] == 1.0 && alpha[1] == 0.0)) {  // B *= alpha (level3_impl.h:174-175)
     GemmCall c;
