@@ -6,11 +6,16 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "../../include/eigen_amd_blas.h"
 #include "gemm_launch.hpp"
@@ -96,14 +101,97 @@ int ensure_device() {
   return EIGAMD_OK;
 }
 
-// Device staging buffers for host-pointer calls: grow-only, owned by the
-// process, guarded by one mutex (callers may invoke ?gemm_ from several host
-// threads; the reference entry points are re-entrant).
+// A few host threads that copy between the caller's (pageable) matrices and pinned
+// staging memory: one thread moves ~10 GB/s, PCIe moves five times that.
+class CopyPool {
+ public:
+  explicit CopyPool(int nthreads) {
+    for (int t = 0; t < nthreads; ++t) workers_.emplace_back([this] { loop(); });
+  }
+  ~CopyPool() {
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& w : workers_) w.join();
+  }
+  // fn(i) for i in [0, n), spread over the workers and the calling thread; returns when all ran.
+  void parallel_for(int64_t n, const std::function<void(int64_t)>& fn) {
+    if (n <= 0) return;
+    if (workers_.empty() || n == 1) {
+      for (int64_t i = 0; i < n; ++i) fn(i);
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      fn_ = &fn;
+      n_ = n;
+      next_ = 0;
+      active_ = (int)workers_.size();
+      ++generation_;
+    }
+    cv_.notify_all();
+    drain();
+    std::unique_lock<std::mutex> l(mu_);
+    done_cv_.wait(l, [this] { return active_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  void drain() {
+    for (;;) {
+      const int64_t i = next_.fetch_add(1);
+      if (i >= n_) break;
+      (*fn_)(i);
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> l(mu_);
+        cv_.wait(l, [&] { return stop_ || generation_ != seen; });
+        if (stop_) return;
+        seen = generation_;
+      }
+      drain();
+      {
+        std::lock_guard<std::mutex> l(mu_);
+        --active_;
+      }
+      done_cv_.notify_all();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_cv_;
+  const std::function<void(int64_t)>* fn_ = nullptr;
+  int64_t n_ = 0;
+  std::atomic<int64_t> next_{0};
+  int active_ = 0;
+  uint64_t generation_ = 0;
+  bool stop_ = false;
+};
+
+// Per-process handle of the host-pointer entry points: grow-only device buffers, pinned
+// staging chunks (two per direction), three streams, the copy threads.  Guarded by one
+// mutex (callers may invoke ?gemm_ from several host threads; the reference entry points
+// are re-entrant).
 struct Staging {
+  static constexpr size_t kChunk = 64u << 20;
   std::mutex mu;
   void* buf[3] = {nullptr, nullptr, nullptr};
   size_t cap[3] = {0, 0, 0};
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;   // compute
+  hipStream_t h2d = nullptr, d2h = nullptr;
+  void* up[2] = {nullptr, nullptr};
+  void* down[2] = {nullptr, nullptr};
+  hipEvent_t up_free[2] = {nullptr, nullptr};     // the DMA out of up[i] has finished
+  hipEvent_t down_ready[2] = {nullptr, nullptr};  // the DMA into down[i] has finished
+  hipEvent_t uploaded = nullptr, computed = nullptr;
+  int up_next = 0, down_next = 0;
+  CopyPool* pool = nullptr;
   int reserve(int i, size_t bytes) {
     if (bytes <= cap[i]) return EIGAMD_OK;
     if (buf[i]) { HIP_TRY(hipFree(buf[i])); buf[i] = nullptr; cap[i] = 0; }
@@ -111,6 +199,94 @@ struct Staging {
     HIP_TRY(hipMalloc(&buf[i], want));
     cap[i] = want;
     return EIGAMD_OK;
+  }
+  int init() {
+    if (stream) return EIGAMD_OK;
+    HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&h2d, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&d2h, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      HIP_TRY(hipHostMalloc(&up[i], kChunk, hipHostMallocDefault));
+      HIP_TRY(hipHostMalloc(&down[i], kChunk, hipHostMallocDefault));
+      HIP_TRY(hipEventCreateWithFlags(&up_free[i], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&down_ready[i], hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(up_free[i], h2d));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&uploaded, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&computed, hipEventDisableTiming));
+    int nthreads = 8;
+    if (const char* e = getenv("EIGAMD_HOST_THREADS")) nthreads = std::max(1, atoi(e));
+    pool = new CopyPool(nthreads - 1);
+    return EIGAMD_OK;
+  }
+
+  // rows x cols elements of `es` bytes from host (leading dimension ld) to device (dld),
+  // through the pinned chunks, asynchronously on the h2d stream.
+  int upload(void* dev, int64_t dld, const void* host, int64_t ld, int64_t rows, int64_t cols, int es) {
+    if (rows <= 0 || cols <= 0) return EIGAMD_OK;
+    const size_t colbytes = (size_t)rows * es;
+    if (colbytes > kChunk) {  // a single column does not fit a chunk: let the runtime stage it
+      HIP_TRY(hipMemcpy2DAsync(dev, dld * es, host, ld * es, colbytes, cols, hipMemcpyHostToDevice, h2d));
+      return EIGAMD_OK;
+    }
+    const int64_t per = std::max<int64_t>(1, (int64_t)(kChunk / colbytes));
+    for (int64_t c0 = 0; c0 < cols; c0 += per) {
+      const int64_t nc = std::min(per, cols - c0);
+      const int i = up_next;
+      up_next ^= 1;
+      HIP_TRY(hipEventSynchronize(up_free[i]));
+      char* pin = static_cast<char*>(up[i]);
+      const char* src = static_cast<const char*>(host) + (size_t)c0 * ld * es;
+      copy_columns(pin, colbytes, src, (size_t)ld * es, colbytes, nc);
+      HIP_TRY(hipMemcpy2DAsync(static_cast<char*>(dev) + (size_t)c0 * dld * es, dld * es, pin, colbytes, colbytes, nc,
+                               hipMemcpyHostToDevice, h2d));
+      HIP_TRY(hipEventRecord(up_free[i], h2d));
+    }
+    return EIGAMD_OK;
+  }
+
+  // The reverse, on the d2h stream; returns when the data is in the caller's memory.  The DMA
+  // of chunk c+1 runs while the threads copy chunk c out of its pinned buffer.
+  int download(void* host, int64_t ld, const void* dev, int64_t dld, int64_t rows, int64_t cols, int es) {
+    if (rows <= 0 || cols <= 0) return EIGAMD_OK;
+    const size_t colbytes = (size_t)rows * es;
+    if (colbytes > kChunk) {
+      HIP_TRY(hipMemcpy2DAsync(host, ld * es, dev, dld * es, colbytes, cols, hipMemcpyDeviceToHost, d2h));
+      HIP_TRY(hipStreamSynchronize(d2h));
+      return EIGAMD_OK;
+    }
+    const int64_t per = std::max<int64_t>(1, (int64_t)(kChunk / colbytes));
+    auto issue = [&](int64_t c0, int i) -> int {
+      const int64_t nc = std::min(per, cols - c0);
+      HIP_TRY(hipMemcpy2DAsync(down[i], colbytes, static_cast<const char*>(dev) + (size_t)c0 * dld * es, dld * es, colbytes,
+                               nc, hipMemcpyDeviceToHost, d2h));
+      HIP_TRY(hipEventRecord(down_ready[i], d2h));
+      return EIGAMD_OK;
+    };
+    int rc = issue(0, 0);
+    if (rc != EIGAMD_OK) return rc;
+    int cur = 0;
+    for (int64_t c0 = 0; c0 < cols; c0 += per) {
+      const int64_t nc = std::min(per, cols - c0);
+      if (c0 + per < cols && (rc = issue(c0 + per, cur ^ 1)) != EIGAMD_OK) return rc;
+      HIP_TRY(hipEventSynchronize(down_ready[cur]));
+      copy_columns(static_cast<char*>(host) + (size_t)c0 * ld * es, (size_t)ld * es, static_cast<const char*>(down[cur]),
+                   colbytes, colbytes, nc);
+      cur ^= 1;
+    }
+    return EIGAMD_OK;
+  }
+
+ private:
+  // ncols columns of `bytes` bytes each; split into pieces so that all threads have work.
+  void copy_columns(char* dst, size_t dst_pitch, const char* src, size_t src_pitch, size_t bytes, int64_t ncols) {
+    const size_t piece = 1u << 20;
+    const int64_t per_col = (int64_t)((bytes + piece - 1) / piece);
+    pool->parallel_for(ncols * per_col, [&](int64_t t) {
+      const int64_t c = t / per_col, q = t % per_col;
+      const size_t off = (size_t)q * piece, len = std::min(piece, bytes - off);
+      std::memcpy(dst + (size_t)c * dst_pitch + off, src + (size_t)c * src_pitch + off, len);
+    });
   }
 };
 Staging& staging() {
@@ -140,36 +316,63 @@ int gemm_host_impl(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k,
 
   Staging& st = staging();
   std::lock_guard<std::mutex> lock(st.mu);
-  if (!st.stream) HIP_TRY(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
+  if ((rc = st.init()) != EIGAMD_OK) return rc;
   if (k > 0) {
     if ((rc = st.reserve(0, (size_t)dlda * a_cols * es)) != EIGAMD_OK) return rc;
     if ((rc = st.reserve(1, (size_t)dldb * b_cols * es)) != EIGAMD_OK) return rc;
   }
   if ((rc = st.reserve(2, (size_t)dldc * n * es)) != EIGAMD_OK) return rc;
 
-  if (k > 0) {
-    HIP_TRY(hipMemcpy2DAsync(st.buf[0], dlda * es, a, lda * es, a_rows * es, a_cols,
-                             hipMemcpyHostToDevice, st.stream));
-    HIP_TRY(hipMemcpy2DAsync(st.buf[1], dldb * es, b, ldb * es, b_rows * es, b_cols,
-                             hipMemcpyHostToDevice, st.stream));
+  // Pipeline over column panels of C: while the kernel works on panel j, the host threads
+  // stage panel j+1 (B and, unless beta == 0, C) and bring panel j-1 back.  A goes first.
+  if (k > 0 && (rc = st.upload(st.buf[0], dlda, a, lda, a_rows, a_cols, es)) != EIGAMD_OK) return rc;
+  int64_t panel = round_up(std::max<int64_t>(1, (int64_t)(256u << 20) / std::max<int64_t>(1, m * es)), 256);
+  panel = std::min(panel, n);
+  hipEvent_t computed[2] = {st.computed, nullptr};
+  HIP_TRY(hipEventCreateWithFlags(&computed[1], hipEventDisableTiming));
+  auto cpanel = [&](int64_t j0) { return static_cast<char*>(st.buf[2]) + (size_t)j0 * dldc * es; };
+  auto fetch = [&](int64_t j0, int slot) -> int {  // panel [j0, j0 + nb) of C back to the caller
+    const int64_t nb = std::min(panel, n - j0);
+    HIP_TRY(hipStreamWaitEvent(st.d2h, computed[slot], 0));
+    // Only the m x n window goes back: rows m..ldc-1 of C keep the caller's bytes.
+    return st.download(static_cast<char*>(c) + (size_t)j0 * ldc * es, ldc, cpanel(j0), dldc, m, nb, es);
+  };
+  int slot = 0;
+  int64_t prev = -1;
+  for (int64_t j0 = 0; j0 < n; j0 += panel, slot ^= 1) {
+    const int64_t nb = std::min(panel, n - j0);
+    const char* bdev = static_cast<const char*>(st.buf[1]);
+    if (k > 0) {
+      if (stored_rows_is_m(opb))  // B is k x n: columns j0..
+        rc = st.upload(const_cast<char*>(bdev) + (size_t)j0 * dldb * es, dldb,
+                       static_cast<const char*>(b) + (size_t)j0 * ldb * es, ldb, k, nb, es);
+      else                        // B is n x k: rows j0..
+        rc = st.upload(const_cast<char*>(bdev) + (size_t)j0 * es, dldb, static_cast<const char*>(b) + (size_t)j0 * es, ldb,
+                       nb, k, es);
+      if (rc != EIGAMD_OK) return rc;
+    }
+    if (!beta_is_zero &&
+        (rc = st.upload(cpanel(j0), dldc, static_cast<const char*>(c) + (size_t)j0 * ldc * es, ldc, m, nb, es)) != EIGAMD_OK)
+      return rc;
+    HIP_TRY(hipEventRecord(st.uploaded, st.h2d));
+    HIP_TRY(hipStreamWaitEvent(st.stream, st.uploaded, 0));
+    GemmCall call;
+    call.kind = dtype; call.opa = opa; call.opb = opb;
+    call.m = m; call.n = nb; call.k = k;
+    call.alpha[0] = alpha[0]; call.alpha[1] = alpha[1];
+    call.beta[0] = beta[0]; call.beta[1] = beta[1];
+    call.A = st.buf[0]; call.lda = dlda;
+    call.B = stored_rows_is_m(opb) ? bdev + (size_t)j0 * dldb * es : bdev + (size_t)j0 * es;
+    call.ldb = dldb;
+    call.C = cpanel(j0); call.ldc = dldc;
+    HIP_TRY(launch(call, st.stream));
+    HIP_TRY(hipEventRecord(computed[slot], st.stream));
+    if (prev >= 0 && (rc = fetch(prev, slot ^ 1)) != EIGAMD_OK) return rc;
+    prev = j0;
   }
-  if (!beta_is_zero)
-    HIP_TRY(hipMemcpy2DAsync(st.buf[2], dldc * es, c, ldc * es, m * es, n, hipMemcpyHostToDevice,
-                             st.stream));
-  GemmCall call;
-  call.kind = dtype; call.opa = opa; call.opb = opb;
-  call.m = m; call.n = n; call.k = k;
-  call.alpha[0] = alpha[0]; call.alpha[1] = alpha[1];
-  call.beta[0] = beta[0]; call.beta[1] = beta[1];
-  call.A = st.buf[0]; call.lda = dlda;
-  call.B = st.buf[1]; call.ldb = dldb;
-  call.C = st.buf[2]; call.ldc = dldc;
-  HIP_TRY(launch(call, st.stream));
-  // Only the m x n window goes back: rows m..ldc-1 of C keep the caller's bytes.
-  HIP_TRY(hipMemcpy2DAsync(c, ldc * es, st.buf[2], dldc * es, m * es, n, hipMemcpyDeviceToHost,
-                           st.stream));
-  HIP_TRY(hipStreamSynchronize(st.stream));
-  return EIGAMD_OK;
+  rc = fetch(prev, slot ^ 1);
+  HIP_TRY(hipEventDestroy(computed[1]));
+  return rc;
 }
 
 int op_of(char ch) {  // blas/common.h:47-50
@@ -362,15 +565,17 @@ static int lu_host_impl(int dtype, int64_t m, int64_t n, void* a, int64_t lda, i
   const int64_t size = std::min(m, n);
   Staging& st = staging();
   std::lock_guard<std::mutex> lock(st.mu);
-  if (!st.stream) HIP_TRY(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
+  if ((rc = st.init()) != EIGAMD_OK) return rc;
   if ((rc = st.reserve(2, (size_t)dld * n * es)) != EIGAMD_OK) return rc;
   if ((rc = st.reserve(0, (size_t)size * sizeof(int) + 64)) != EIGAMD_OK) return rc;
-  HIP_TRY(hipMemcpy2DAsync(st.buf[2], dld * es, a, lda * es, m * es, n, hipMemcpyHostToDevice, st.stream));
+  if ((rc = st.upload(st.buf[2], dld, a, lda, m, n, es)) != EIGAMD_OK) return rc;
+  HIP_TRY(hipEventRecord(st.uploaded, st.h2d));
+  HIP_TRY(hipStreamWaitEvent(st.stream, st.uploaded, 0));
   HIP_TRY(getrf_device(dtype, m, n, st.buf[2], dld, static_cast<int*>(st.buf[0]), 256, first_zero_pivot,
                        nb_transpositions, st.stream));
-  HIP_TRY(hipMemcpy2DAsync(a, lda * es, st.buf[2], dld * es, m * es, n, hipMemcpyDeviceToHost, st.stream));
   HIP_TRY(hipMemcpyAsync(transp, st.buf[0], (size_t)size * sizeof(int), hipMemcpyDeviceToHost, st.stream));
-  HIP_TRY(hipStreamSynchronize(st.stream));
+  HIP_TRY(hipStreamSynchronize(st.stream));   // getrf_device has synchronised already; this covers the copy
+  if ((rc = st.download(a, lda, st.buf[2], dld, m, n, es)) != EIGAMD_OK) return rc;
   return EIGAMD_OK;
 }
 
@@ -442,16 +647,18 @@ static int trsm_host_impl(int dtype, int side, int uplo, int op, int diag, int64
   const int64_t dlda = round_up(na, 16), dldb = round_up(m, 16);
   Staging& st = staging();
   std::lock_guard<std::mutex> lock(st.mu);
-  if (!st.stream) HIP_TRY(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
+  if ((rc = st.init()) != EIGAMD_OK) return rc;
   if ((rc = st.reserve(0, (size_t)dlda * na * es)) != EIGAMD_OK) return rc;
   if ((rc = st.reserve(2, (size_t)dldb * n * es)) != EIGAMD_OK) return rc;
-  HIP_TRY(hipMemcpy2DAsync(st.buf[0], dlda * es, a, lda * es, na * es, na, hipMemcpyHostToDevice, st.stream));
-  HIP_TRY(hipMemcpy2DAsync(st.buf[2], dldb * es, b, ldb * es, m * es, n, hipMemcpyHostToDevice, st.stream));
+  if ((rc = st.upload(st.buf[0], dlda, a, lda, na, na, es)) != EIGAMD_OK) return rc;
+  if ((rc = st.upload(st.buf[2], dldb, b, ldb, m, n, es)) != EIGAMD_OK) return rc;
+  HIP_TRY(hipEventRecord(st.uploaded, st.h2d));
+  HIP_TRY(hipStreamWaitEvent(st.stream, st.uploaded, 0));
   HIP_TRY(trsm_device(dtype, side == 0, uplo == 0, op, diag == 1, m, n, alpha, st.buf[0], dlda, st.buf[2], dldb, st.stream));
   // only the m x n window goes back
-  HIP_TRY(hipMemcpy2DAsync(b, ldb * es, st.buf[2], dldb * es, m * es, n, hipMemcpyDeviceToHost, st.stream));
-  HIP_TRY(hipStreamSynchronize(st.stream));
-  return EIGAMD_OK;
+  HIP_TRY(hipEventRecord(st.computed, st.stream));
+  HIP_TRY(hipStreamWaitEvent(st.d2h, st.computed, 0));
+  return st.download(b, ldb, st.buf[2], dldb, m, n, es);
 }
 
 static int f77_trsm(int dtype, const char* name, const char* side, const char* uplo, const char* opa, const char* diag,
