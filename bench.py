@@ -177,6 +177,26 @@ def trsm_measurement(n):
     return {f"dtrsm_llnn_{n}_tflops": round(float(n) ** 3 / best / 1e9, 2)}
 
 
+def syrk_measurement(n):
+    """dsyrk('L','N') with an n x n triangle and k = n resident in HBM (eigamd_syrk_dev);
+    n^2 k flop.  Off-diagonal squares are plain GEMM launches, 256-wide diagonal leaves the
+    guarded kernel with a row/column predicate."""
+    import torch
+    import eigen_amd
+    from eigen_amd.device import DeviceMatrix, syrk_dev
+    a = DeviceMatrix(n, n, eigen_amd.F64).fill_uniform(7)
+    c = DeviceMatrix(n, n, eigen_amd.F64).fill_uniform(8)
+    best = 1e30
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        syrk_dev("L", "N", 1.0, a, 1.0, c)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return {f"dsyrk_ln_{n}_tflops": round(float(n) ** 3 / best / 1e9, 2)}
+
+
 def lu_measurement(n):
     """PartialPivLU-equivalent factorisation (eigamd_getrf_dev) of an n x n double matrix
     resident in HBM; 2/3 n^3 flop.  The trailing updates run on the GEMM kernel."""
@@ -362,6 +382,7 @@ def main():
                 }
                 out["extra"].update(lu_measurement(32768))
                 out["extra"].update(trsm_measurement(16384))
+                out["extra"].update(syrk_measurement(16384))
                 out["extra"]["sgemm_pct_of_peak"] = round(100 * out["extra"]["sgemm_16384_tflops"] / PEAK_TFLOPS["f32"], 2)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args)

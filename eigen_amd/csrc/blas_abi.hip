@@ -21,6 +21,7 @@
 #include "gemm_launch.hpp"
 #include "lu.hpp"
 #include "trsm.hpp"
+#include "syrk.hpp"
 #include "rng.hpp"
 
 using namespace eigamd;
@@ -701,6 +702,91 @@ int ctrsm_(const char* side, const char* uplo, const char* opa, const char* diag
 int ztrsm_(const char* side, const char* uplo, const char* opa, const char* diag, const int* m, const int* n,
            const double* alpha, const double* a, const int* lda, double* b, const int* ldb) {
   return f77_trsm(C64, "ZTRSM ", side, uplo, opa, diag, m, n, alpha, a, lda, b, ldb);
+}
+
+// ---- ?syrk_ (blas/level3_impl.h:357-433) ---------------------------------------------
+
+int eigamd_syrk_dev(int dtype, int uplo, int op, int64_t n, int64_t k, const void* alpha, const void* d_a, int64_t lda,
+                    const void* beta, void* d_c, int64_t ldc, void* stream) {
+  if (dtype < 0 || dtype > 3) return fail(EIGAMD_ERR_ARG, "dtype out of range");
+  if (uplo < 0 || uplo > 1 || (op != OP_N && op != OP_T) || n < 0 || k < 0 ||
+      lda < std::max<int64_t>(1, op == OP_N ? n : k) || ldc < std::max<int64_t>(1, n) || n > 0x7fffffff || k > 0x7fffffff)
+    return fail(EIGAMD_ERR_ARG, "invalid syrk arguments");
+  if (n == 0) return EIGAMD_OK;
+  int rc = ensure_device();
+  if (rc != EIGAMD_OK) return rc;
+  double al[2], be[2];
+  read_scalar(dtype, alpha, al);
+  read_scalar(dtype, beta, be);
+  HIP_TRY(syrk_device(dtype, uplo == 0, op, n, k, al, d_a, lda, be, d_c, ldc, static_cast<hipStream_t>(stream)));
+  return EIGAMD_OK;
+}
+
+static int syrk_host_impl(int dtype, int uplo, int op, int64_t n, int64_t k, const double alpha[2], const void* a,
+                          int64_t lda, const double beta[2], void* c, int64_t ldc) {
+  int rc = ensure_device();
+  if (rc != EIGAMD_OK) return rc;
+  const int es = kElemSize[dtype];
+  const int64_t a_rows = op == OP_N ? n : k, a_cols = op == OP_N ? k : n;
+  const int64_t dlda = round_up(std::max<int64_t>(a_rows, 1), 16), dldc = round_up(n, 16);
+  Staging& st = staging();
+  std::lock_guard<std::mutex> lock(st.mu);
+  if ((rc = st.init()) != EIGAMD_OK) return rc;
+  if (k > 0 && (rc = st.reserve(0, (size_t)dlda * a_cols * es)) != EIGAMD_OK) return rc;
+  if ((rc = st.reserve(2, (size_t)dldc * n * es)) != EIGAMD_OK) return rc;
+  if (k > 0 && (rc = st.upload(st.buf[0], dlda, a, lda, a_rows, a_cols, es)) != EIGAMD_OK) return rc;
+  // the whole n x n window travels both ways; the kernels touch the uplo triangle only, so
+  // the other triangle comes back with the bytes it went out with
+  if ((rc = st.upload(st.buf[2], dldc, c, ldc, n, n, es)) != EIGAMD_OK) return rc;
+  HIP_TRY(hipEventRecord(st.uploaded, st.h2d));
+  HIP_TRY(hipStreamWaitEvent(st.stream, st.uploaded, 0));
+  HIP_TRY(syrk_device(dtype, uplo == 0, op, n, k, alpha, st.buf[0], dlda, beta, st.buf[2], dldc, st.stream));
+  HIP_TRY(hipEventRecord(st.computed, st.stream));
+  HIP_TRY(hipStreamWaitEvent(st.d2h, st.computed, 0));
+  return st.download(c, ldc, st.buf[2], dldc, n, n, es);
+}
+
+static int f77_syrk(int dtype, const char* name, const char* uplo, const char* opc, const int* n, const int* k,
+                    const void* alpha, const void* a, const int* lda, const void* beta, void* c, const int* ldc) {
+  const int ul = uplo_of(*uplo);
+  int op = op_of(*opc);
+  int info = 0;                                                    // level3_impl.h:386-394
+  if (ul < 0) info = 1;
+  else if (op < 0 || (dtype >= C32 && op == OP_C)) info = 2;
+  else if (*n < 0) info = 3;
+  else if (*k < 0) info = 4;
+  else if (*lda < std::max(1, op == OP_N ? *n : *k)) info = 7;
+  else if (*ldc < std::max(1, *n)) info = 10;
+  if (info) return xerbla_(name, &info, 6);
+  if (op == OP_C) op = OP_T;   // real kinds: 'C' is 'T'
+  if (*n == 0) return 0;
+  double al[2], be[2];
+  read_scalar(dtype, alpha, al);
+  read_scalar(dtype, beta, be);
+  if (*k == 0 && be[0] == 1.0 && be[1] == 0.0) return 0;          // level3_impl.h:396,406
+  int rc = syrk_host_impl(dtype, ul, op, *n, *k, al, a, *lda, be, c, *ldc);
+  if (rc != EIGAMD_OK) {
+    std::fprintf(stderr, "eigen_amd %s: %s\n", name, g_err.c_str());
+    std::abort();
+  }
+  return 0;
+}
+
+int ssyrk_(const char* uplo, const char* trans, const int* n, const int* k, const float* alpha, const float* a,
+           const int* lda, const float* beta, float* c, const int* ldc) {
+  return f77_syrk(F32, "SSYRK ", uplo, trans, n, k, alpha, a, lda, beta, c, ldc);
+}
+int dsyrk_(const char* uplo, const char* trans, const int* n, const int* k, const double* alpha, const double* a,
+           const int* lda, const double* beta, double* c, const int* ldc) {
+  return f77_syrk(F64, "DSYRK ", uplo, trans, n, k, alpha, a, lda, beta, c, ldc);
+}
+int csyrk_(const char* uplo, const char* trans, const int* n, const int* k, const float* alpha, const float* a,
+           const int* lda, const float* beta, float* c, const int* ldc) {
+  return f77_syrk(C32, "CSYRK ", uplo, trans, n, k, alpha, a, lda, beta, c, ldc);
+}
+int zsyrk_(const char* uplo, const char* trans, const int* n, const int* k, const double* alpha, const double* a,
+           const int* lda, const double* beta, double* c, const int* ldc) {
+  return f77_syrk(C64, "ZSYRK ", uplo, trans, n, k, alpha, a, lda, beta, c, ldc);
 }
 
 const char* eigamd_last_error(void) { return g_err.c_str(); }

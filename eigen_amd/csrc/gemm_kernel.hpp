@@ -46,6 +46,7 @@ struct GemmParams {
   int conj_a, conj_b;     // complex only: conjugate the operand's elements
   int group_m;            // tile rows walked together by consecutive blocks (L2 reuse)
   int xcd_remap;          // 1: give each XCD a contiguous run of the tile sequence
+  int tri;                // guarded kernels only: 0 all of C, 1 only row >= col, 2 only row <= col
 };
 
 // Tile geometry per scalar kind.  WM x WN wavefronts per workgroup, each owning
@@ -484,6 +485,9 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
   // (blas/level3_impl.h:64: NaN/Inf in C must not propagate).  Per column group j the
   // loads of C are issued together, then combined and stored.
   const bool use_c = p.beta[0] != 0.0 || p.beta[1] != 0.0;
+  // Triangular destinations (the symmetric rank-k update): elements outside the triangle are
+  // neither read nor written.
+  auto in_tri = [&](int row, int col) { return !GUARD || p.tri == 0 || (p.tri == 1 ? row >= col : row <= col); };
   const int mrow = wm0 + xi;                       // + i * TM
   const int nrow = wn0 + acc_row<KIND>(0, kk);     // + j * TM + acc_row(r, 0)
   Elem* __restrict__ cbase = static_cast<Elem*>(p.C) + (int64_t)(m0 + mrow) + (int64_t)(n0 + nrow) * p.ldc;
@@ -500,7 +504,8 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
         for (int r = 0; r < T::NACC; ++r) {
           const int nn = j * TM + acc_row<KIND>(r, 0);
           Elem z = {};
-          cv[i][r] = (!GUARD || (mrow + i * TM < mrem && nrow + nn < nrem)) ? cbase[i * TM + (int64_t)nn * p.ldc] : z;
+          cv[i][r] = (!GUARD || (mrow + i * TM < mrem && nrow + nn < nrem && in_tri(m0 + mrow + i * TM, n0 + nrow + nn)))
+                         ? cbase[i * TM + (int64_t)nn * p.ldc] : z;
         }
     }
 #pragma unroll
@@ -521,7 +526,8 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
             v.y += ber * cv[i][r].y + bei * cv[i][r].x;
           }
         }
-        if (!GUARD || (mrow + i * TM < mrem && nrow + nn < nrem)) cbase[i * TM + (int64_t)nn * p.ldc] = v;
+        if (!GUARD || (mrow + i * TM < mrem && nrow + nn < nrem && in_tri(m0 + mrow + i * TM, n0 + nrow + nn)))
+          cbase[i * TM + (int64_t)nn * p.ldc] = v;
       }
   }
 }
@@ -529,7 +535,7 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
 // C = beta * C over an m x n window (the k == 0 case of the BLAS wrapper,
 // blas/level3_impl.h:62-69).
 template <int KIND>
-__global__ void scale_kernel(void* Cv, int64_t ldc, int M, int N, double beta_re, double beta_im) {
+__global__ void scale_kernel(void* Cv, int64_t ldc, int M, int N, double beta_re, double beta_im, int tri) {
   typedef typename Traits<KIND>::Elem Elem;
   typedef typename Traits<KIND>::Real Real;
   Elem* C = static_cast<Elem*>(Cv);
@@ -537,6 +543,7 @@ __global__ void scale_kernel(void* Cv, int64_t ldc, int M, int N, double beta_re
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t n = idx / M, m = idx - n * M;
+    if (tri != 0 && (tri == 1 ? m < n : m > n)) continue;
     Elem* dst = C + m + n * ldc;
     if constexpr (!Traits<KIND>::kCplx) {
       *dst = beta_re == 0.0 ? (Real)0 : (Real)beta_re * *dst;

@@ -21,6 +21,7 @@ struct GemmCall {
   const void* A; int64_t lda;
   const void* B; int64_t ldb;
   void* C; int64_t ldc;
+  int tri = 0;  // 1 / 2: write (and read) only the lower / upper triangle of C (row >= col / row <= col)
 };
 
 // Block-to-tile mapping knobs; the defaults are what the shipped library uses, the
@@ -69,6 +70,7 @@ static hipError_t launch_region(const GemmCall& c, int64_t r0, int64_t c0, int64
   p.conj_b = (c.opb == OP_C || c.opb == OP_CONJ);
   p.group_m = tuning().group_m;
   p.xcd_remap = tuning().xcd_remap;
+  p.tri = GUARD ? c.tri : 0;
   const int64_t nblk = (int64_t)p.tiles_m * p.tiles_n;
   if (nblk > 0x7fffffff) return hipErrorInvalidValue;
   hipLaunchKernelGGL((gemm_kernel<KIND, AK, BKC, GUARD>), dim3((unsigned)nblk), dim3(G::THREADS),
@@ -82,8 +84,9 @@ static hipError_t launch_layout(const GemmCall& c, hipStream_t stream) {
   constexpr int ES = G::ES;
   const bool aligned = ((uintptr_t)c.A % 16 == 0) && ((uintptr_t)c.B % 16 == 0) &&
                        ((c.lda * ES) % 16 == 0) && ((c.ldb * ES) % 16 == 0);
-  const int64_t mi = aligned ? (c.m / G::BM) * G::BM : 0;
-  const int64_t ni = aligned ? (c.n / G::BN) * G::BN : 0;
+  // a triangular destination is one guarded launch (indices relative to C's origin)
+  const int64_t mi = aligned && c.tri == 0 ? (c.m / G::BM) * G::BM : 0;
+  const int64_t ni = aligned && c.tri == 0 ? (c.n / G::BN) * G::BN : 0;
   hipError_t e;
   if (mi > 0 && ni > 0) {
     e = launch_region<KIND, AK, BKC, false>(c, 0, 0, mi, ni, stream);
@@ -102,7 +105,7 @@ static hipError_t launch_gemm(const GemmCall& c, hipStream_t stream) {
     const int64_t total = c.m * c.n;
     const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     hipLaunchKernelGGL((scale_kernel<KIND>), dim3(blocks), dim3(256), 0, stream, c.C, c.ldc,
-                       (int)c.m, (int)c.n, c.beta[0], c.beta[1]);
+                       (int)c.m, (int)c.n, c.beta[0], c.beta[1], c.tri);
     return hipGetLastError();
   }
   const bool ak = (c.opa == OP_T || c.opa == OP_C);    // op(A) = A^T / A^H: k runs fastest

@@ -1,0 +1,15 @@
+// Symmetric rank-k update on the device (syrk.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace eigamd {
+
+// C <- alpha * A * A^T + beta * C (op = OP_N, A is n x k) or alpha * A^T * A + beta * C
+// (op = OP_T, A is k x n) on the `upper` or lower triangle of the n x n matrix C; the other
+// triangle is neither read nor written.  Plain transpose for the complex kinds as well (the
+// symmetric, not the Hermitian, update).  Asynchronous on `s`.
+hipError_t syrk_device(int kind, bool upper, int op, int64_t n, int64_t k, const double alpha[2], const void* A,
+                       int64_t lda, const double beta[2], void* C, int64_t ldc, hipStream_t s);
+
+}  // namespace eigamd

@@ -99,3 +99,18 @@ def trsm_dev(side, uplo, transa, diag, alpha, a, b, stream=None):
                              ctypes.c_void_p(a.ptr), a.ld, ctypes.c_void_p(b.ptr), b.ld, _stream_ptr(stream))
     _lib.check(rc, "eigamd_trsm_dev")
     return b
+
+
+def syrk_dev(uplo, trans, alpha, a, beta, c, stream=None):
+    """c <- alpha * a * a^T + beta * c (trans 'N') or alpha * a^T * a + beta * c (trans 'T') on
+    the uplo triangle of the square DeviceMatrix c (``eigamd_syrk_dev``)."""
+    if a.kind != c.kind:
+        raise ValueError("operands must share one scalar kind")
+    dt = _NP_OF_KIND[c.kind]
+    al, be = np.array([alpha], dtype=dt), np.array([beta], dtype=dt)
+    k = a.cols if trans.upper() == "N" else a.rows
+    rc = lib.eigamd_syrk_dev(c.kind, "UL".index(uplo.upper()), _OPCODE[trans.upper()], c.rows, k,
+                             ctypes.c_void_p(al.ctypes.data), ctypes.c_void_p(a.ptr), a.ld,
+                             ctypes.c_void_p(be.ctypes.data), ctypes.c_void_p(c.ptr), c.ld, _stream_ptr(stream))
+    _lib.check(rc, "eigamd_syrk_dev")
+    return c

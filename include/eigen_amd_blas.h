@@ -149,6 +149,28 @@ int ztrsm_(const char* side, const char* uplo, const char* transa, const char* d
 int eigamd_trsm_dev(int dtype, int side, int uplo, int op, int diag, int64_t m, int64_t n, const void* alpha,
                     const void* d_a, int64_t lda, void* d_b, int64_t ldb, void* stream);
 
+/* ---- symmetric rank-k update ----------------------------------------------------
+ *
+ * ssyrk_/dsyrk_/csyrk_/zsyrk_ replace EIGEN_BLAS_FUNC(syrk) (blas/level3_impl.h:357-433):
+ * C <- alpha A A^T + beta C (trans 'N', A n x k) or alpha A^T A + beta C (trans 'T'; 'C' too
+ * for the real kinds, an error for the complex ones as in the reference) on the uplo
+ * triangle of the n x n matrix C; the other triangle is neither read nor written.  xerbla_
+ * codes 1 uplo, 2 trans, 3 n, 4 k, 7 lda, 10 ldc.  {s,d}syrk_ are what Eigen's
+ * GeneralMatrixMatrixTriangular_BLAS.h:49-147 binds under EIGEN_USE_BLAS.
+ *
+ * eigamd_syrk_dev: the same on matrices already in HBM (op is EIGAMD_OP_N or EIGAMD_OP_T),
+ * asynchronous on `stream`. */
+int ssyrk_(const char* uplo, const char* trans, const int* n, const int* k, const float* alpha, const float* a,
+           const int* lda, const float* beta, float* c, const int* ldc);
+int dsyrk_(const char* uplo, const char* trans, const int* n, const int* k, const double* alpha, const double* a,
+           const int* lda, const double* beta, double* c, const int* ldc);
+int csyrk_(const char* uplo, const char* trans, const int* n, const int* k, const float* alpha, const float* a,
+           const int* lda, const float* beta, float* c, const int* ldc);
+int zsyrk_(const char* uplo, const char* trans, const int* n, const int* k, const double* alpha, const double* a,
+           const int* lda, const double* beta, double* c, const int* ldc);
+int eigamd_syrk_dev(int dtype, int uplo, int op, int64_t n, int64_t k, const void* alpha, const void* d_a, int64_t lda,
+                    const void* beta, void* d_c, int64_t ldc, void* stream);
+
 /* ---- misc --------------------------------------------------------------------- */
 const char* eigamd_last_error(void);  /* text of the last failure on this thread */
 int eigamd_device_ok(void);           /* 1 if a gfx950 device is usable, else 0 */

@@ -21,6 +21,9 @@ typedef int (*gemm_fn_t)(const char *, const char *, const int *, const int *, c
 typedef int (*trsm_fn_t)(const char *, const char *, const char *, const char *, const int *, const int *, const void *,
                          const void *, const int *, void *, const int *);
 
+typedef int (*syrk_fn_t)(const char *, const char *, const int *, const int *, const void *, const void *, const int *,
+                         const void *, void *, const int *);
+
 struct netlib_report {
   int ncalls;        /* calls made by ?CHK1 */
   int nfail_same;    /* an argument or C's padding came back changed */
@@ -179,6 +182,33 @@ int netlib_chke_trsm(trsm_fn_t trsm, char letter) {
     netlib_xerbla_info = 0;
     trsm(&rows[r].sd, &rows[r].ul, &rows[r].tr, &rows[r].dg, &rows[r].m, &rows[r].n, single ? (void *)alphaf : (void *)alpha,
          a, &rows[r].lda, b, &rows[r].ldb);
+    if (netlib_xerbla_count != 1 || netlib_xerbla_info != rows[r].infot || strncmp(netlib_xerbla_name, want, 6) != 0)
+      nfail += 1;
+  }
+  netlib_xerbla_count = 0;
+  return nfail;
+}
+
+/* SYRK rows of ?CHKE (dblat3.f:2262-2300): 18 calls. */
+int netlib_chke_syrk(syrk_fn_t syrk, char letter) {
+  static const struct { int infot; char ul, tr; int n, k, lda, ldc; } rows[] = {
+      {1, '/', 'N', 0, 0, 1, 1},  {2, 'U', '/', 0, 0, 1, 1},
+      {3, 'U', 'N', -1, 0, 1, 1}, {3, 'U', 'T', -1, 0, 1, 1}, {3, 'L', 'N', -1, 0, 1, 1}, {3, 'L', 'T', -1, 0, 1, 1},
+      {4, 'U', 'N', 0, -1, 1, 1}, {4, 'U', 'T', 0, -1, 1, 1}, {4, 'L', 'N', 0, -1, 1, 1}, {4, 'L', 'T', 0, -1, 1, 1},
+      {7, 'U', 'N', 2, 0, 1, 2},  {7, 'U', 'T', 0, 2, 1, 1},  {7, 'L', 'N', 2, 0, 1, 2},  {7, 'L', 'T', 0, 2, 1, 1},
+      {10, 'U', 'N', 2, 0, 2, 1}, {10, 'U', 'T', 2, 0, 1, 1}, {10, 'L', 'N', 2, 0, 2, 1}, {10, 'L', 'T', 2, 0, 1, 1},
+  };
+  double a[8] = {0}, c[8] = {0}, alpha[2] = {1, 0}, beta[2] = {2, 0};
+  float alphaf[2] = {1, 0}, betaf[2] = {2, 0};
+  const int single = letter == 'S' || letter == 'C';
+  char want[8];
+  snprintf(want, sizeof want, "%cSYRK ", letter);
+  int nfail = 0;
+  for (unsigned r = 0; r < sizeof rows / sizeof rows[0]; ++r) {
+    netlib_xerbla_count = 0;
+    netlib_xerbla_info = 0;
+    syrk(&rows[r].ul, &rows[r].tr, &rows[r].n, &rows[r].k, single ? (void *)alphaf : (void *)alpha, a, &rows[r].lda,
+         single ? (void *)betaf : (void *)beta, c, &rows[r].ldc);
     if (netlib_xerbla_count != 1 || netlib_xerbla_info != rows[r].infot || strncmp(netlib_xerbla_name, want, 6) != 0)
       nfail += 1;
   }

@@ -1,11 +1,11 @@
-/* CPU oracle for the triangular solve with many right-hand sides (?trsm_): plain C, float,
- * double, complex float, complex double, every side / uplo / trans / diag form.
+/* CPU oracle for the triangular solve with many right-hand sides (?trsm_) and the symmetric
+ * rank-k update (?syrk_): plain C, float, double, complex float, complex double, every form.
  *
  * TEST INFRASTRUCTURE ONLY.  Callers: tests/.  The product library never links this file.
  *
- * Parity pin: checked in tests/test_trsm_oracle.py against (a) the Netlib level-3
- * known-answer driver ?CHK3 restated in netlib_l3.c with the parameter files of
- * blas/testing/?blat3.dat, (b) golden outputs of Eigen's own ?trsm_ committed under
+ * Parity pin: checked in tests/test_trsm_oracle.py and tests/test_syrk_oracle.py against (a)
+ * the Netlib level-3 known-answer drivers ?CHK3 / ?CHK4 restated in netlib_l3.c with the parameter files of
+ * blas/testing/?blat3.dat, (b) golden outputs of Eigen's own ?trsm_ / ?syrk_ committed under
  * tests/golden/, and (c) when oracle/_ref is built, the reference library itself on fresh
  * inputs.  Agreement with the reference is to rounding (the reference evaluates the same
  * recurrences in panels), not bitwise.

@@ -235,6 +235,51 @@ def trsm_residual_ratio(kind, side, uplo, transa, diag, alpha, a, b0, x):
     return float((abs1(r) / (EPS[kind] * g)).max()) if x.size else 0.0
 
 
+def run_netlib_chk4_syrk(kind, syrk_fn, params):
+    """Restated SYRK rows of ?CHK4 over `syrk_fn` (a ctypes function with the ?syrk_ signature)."""
+    real = ctypes.c_float if kind in (0, 2) else ctypes.c_double
+    idim = (ctypes.c_int * len(params["idim"]))(*params["idim"])
+    alf = (real * len(params["alf"]))(*params["alf"])
+    bet = (real * len(params["bet"]))(*params["bet"])
+    per = 2 if params["cplx"] else 1
+    rep = NetlibReport()
+    f = getattr(oracle, "netlib_chk4_syrk_" + SUFFIX[kind])
+    f(ctypes.cast(syrk_fn, ctypes.c_void_p), len(params["idim"]), idim, len(params["alf"]) // per, alf,
+      len(params["bet"]) // per, bet, ctypes.byref(rep))
+    return rep
+
+
+def run_netlib_chke_syrk(kind, syrk_fn):
+    return oracle.netlib_chke_syrk(ctypes.cast(syrk_fn, ctypes.c_void_p), ctypes.c_char("SDCZ"[kind].encode()))
+
+
+def oracle_syrk(kind):
+    return getattr(oracle, "oracle_syrk_" + SUFFIX[kind])
+
+
+def call_f77_syrk(fn, uplo, trans, n, k, alpha, a, lda, beta, c, ldc):
+    """Call any function with the F77 ?syrk_ signature on numpy buffers (c is updated)."""
+    al, be = np.array([alpha], dtype=c.dtype), np.array([beta], dtype=c.dtype)
+    ci = lambda v: ctypes.byref(ctypes.c_int(int(v)))
+    cs = lambda ch: ctypes.c_char_p(ch.encode())
+    fn(cs(uplo), cs(trans), ci(n), ci(k), _vp(al), _vp(a), ci(lda), _vp(be), _vp(c), ci(ldc))
+    return c
+
+
+def syrk_operands(kind, uplo, trans, n, k, seed, pad=0):
+    """A (n x k, or k x n for trans != 'N') and C (n x n) from the library's generator; the
+    triangle of C that ?syrk_ must not touch holds -1e10."""
+    import eigen_amd
+    dt = DTYPES[kind]
+    ar, ac = (n, k) if trans == "N" else (k, n)
+    a = eigen_amd.fill_uniform_host(dt, ar, ac, seed, ld=ar + pad)
+    c = eigen_amd.fill_uniform_host(dt, n, n, seed + 1, ld=n + pad)
+    if n:
+        i, j = np.indices((n, n))
+        c[(i > j) if uplo == "U" else (i < j)] = -1.0e10
+    return a, c
+
+
 def gauge_ratio(kind, got, ref, alpha, a_abs1, b_abs1, beta, c0, k):
     """Componentwise ?MMCH-style ratio |got - ref| / (eps * G) with
     G = abs1(alpha) * (|A| |B|)_ij + abs1(beta) * abs1(c0_ij)."""
