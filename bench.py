@@ -179,8 +179,8 @@ def trsm_measurement(n):
 
 def syrk_measurement(n):
     """dsyrk('L','N') with an n x n triangle and k = n resident in HBM (eigamd_syrk_dev);
-    n^2 k flop.  Off-diagonal squares are plain GEMM launches, 256-wide diagonal leaves the
-    guarded kernel with a row/column predicate."""
+    n^2 k flop.  One GEMM launch: tiles outside the triangle leave at once, diagonal tiles write
+    through a row/column predicate in the epilogue."""
     import torch
     import eigen_amd
     from eigen_amd.device import DeviceMatrix, syrk_dev

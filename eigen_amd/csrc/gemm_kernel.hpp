@@ -46,7 +46,8 @@ struct GemmParams {
   int conj_a, conj_b;     // complex only: conjugate the operand's elements
   int group_m;            // tile rows walked together by consecutive blocks (L2 reuse)
   int xcd_remap;          // 1: give each XCD a contiguous run of the tile sequence
-  int tri;                // guarded kernels only: 0 all of C, 1 only row >= col, 2 only row <= col
+  int tri;                // 0 all of C, 1 only row >= col, 2 only row <= col (indices of the whole C:
+  int tri_r0, tri_c0;     // this launch covers the region that starts at row tri_r0, column tri_c0)
 };
 
 // Tile geometry per scalar kind.  WM x WN wavefronts per workgroup, each owning
@@ -297,6 +298,9 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
   }
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
+  // Triangular destination: a tile that lies wholly outside the triangle has nothing to do.
+  if (p.tri == 1 && p.tri_r0 + m0 + BM - 1 < p.tri_c0 + n0) return;
+  if (p.tri == 2 && p.tri_r0 + m0 > p.tri_c0 + n0 + BN - 1) return;
 
   const Elem* __restrict__ A = static_cast<const Elem*>(p.A);
   const Elem* __restrict__ B = static_cast<const Elem*>(p.B);
@@ -486,8 +490,10 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
   // loads of C are issued together, then combined and stored.
   const bool use_c = p.beta[0] != 0.0 || p.beta[1] != 0.0;
   // Triangular destinations (the symmetric rank-k update): elements outside the triangle are
-  // neither read nor written.
-  auto in_tri = [&](int row, int col) { return !GUARD || p.tri == 0 || (p.tri == 1 ? row >= col : row <= col); };
+  // neither read nor written; only the epilogue knows about it.
+  auto in_tri = [&](int row, int col) {
+    return p.tri == 0 || (p.tri == 1 ? p.tri_r0 + row >= p.tri_c0 + col : p.tri_r0 + row <= p.tri_c0 + col);
+  };
   const int mrow = wm0 + xi;                       // + i * TM
   const int nrow = wn0 + acc_row<KIND>(0, kk);     // + j * TM + acc_row(r, 0)
   Elem* __restrict__ cbase = static_cast<Elem*>(p.C) + (int64_t)(m0 + mrow) + (int64_t)(n0 + nrow) * p.ldc;
@@ -504,7 +510,7 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
         for (int r = 0; r < T::NACC; ++r) {
           const int nn = j * TM + acc_row<KIND>(r, 0);
           Elem z = {};
-          cv[i][r] = (!GUARD || (mrow + i * TM < mrem && nrow + nn < nrem && in_tri(m0 + mrow + i * TM, n0 + nrow + nn)))
+          cv[i][r] = ((!GUARD || (mrow + i * TM < mrem && nrow + nn < nrem)) && in_tri(m0 + mrow + i * TM, n0 + nrow + nn))
                          ? cbase[i * TM + (int64_t)nn * p.ldc] : z;
         }
     }
@@ -526,7 +532,7 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
             v.y += ber * cv[i][r].y + bei * cv[i][r].x;
           }
         }
-        if (!GUARD || (mrow + i * TM < mrem && nrow + nn < nrem && in_tri(m0 + mrow + i * TM, n0 + nrow + nn)))
+        if ((!GUARD || (mrow + i * TM < mrem && nrow + nn < nrem)) && in_tri(m0 + mrow + i * TM, n0 + nrow + nn))
           cbase[i * TM + (int64_t)nn * p.ldc] = v;
       }
   }

@@ -69,8 +69,10 @@ static hipError_t launch_region(const GemmCall& c, int64_t r0, int64_t c0, int64
   p.conj_a = (c.opa == OP_C || c.opa == OP_CONJ);
   p.conj_b = (c.opb == OP_C || c.opb == OP_CONJ);
   p.group_m = tuning().group_m;
-  p.xcd_remap = tuning().xcd_remap;
-  p.tri = GUARD ? c.tri : 0;
+  // A triangular destination leaves about half of the tiles empty: contiguous runs of the tile
+  // sequence per XCD would give the XCDs very different amounts of work, round-robin does not.
+  p.xcd_remap = c.tri ? 0 : tuning().xcd_remap;
+  p.tri = c.tri; p.tri_r0 = (int)r0; p.tri_c0 = (int)c0;
   const int64_t nblk = (int64_t)p.tiles_m * p.tiles_n;
   if (nblk > 0x7fffffff) return hipErrorInvalidValue;
   hipLaunchKernelGGL((gemm_kernel<KIND, AK, BKC, GUARD>), dim3((unsigned)nblk), dim3(G::THREADS),
@@ -84,9 +86,8 @@ static hipError_t launch_layout(const GemmCall& c, hipStream_t stream) {
   constexpr int ES = G::ES;
   const bool aligned = ((uintptr_t)c.A % 16 == 0) && ((uintptr_t)c.B % 16 == 0) &&
                        ((c.lda * ES) % 16 == 0) && ((c.ldb * ES) % 16 == 0);
-  // a triangular destination is one guarded launch (indices relative to C's origin)
-  const int64_t mi = aligned && c.tri == 0 ? (c.m / G::BM) * G::BM : 0;
-  const int64_t ni = aligned && c.tri == 0 ? (c.n / G::BN) * G::BN : 0;
+  const int64_t mi = aligned ? (c.m / G::BM) * G::BM : 0;
+  const int64_t ni = aligned ? (c.n / G::BN) * G::BN : 0;
   hipError_t e;
   if (mi > 0 && ni > 0) {
     e = launch_region<KIND, AK, BKC, false>(c, 0, 0, mi, ni, stream);

@@ -4,16 +4,15 @@
 // (Eigen/src/Core/products/GeneralMatrixMatrixTriangular.h:62-200) behind
 // EIGEN_BLAS_FUNC(syrk) (blas/level3_impl.h:357-433).  The reference runs its GEMM
 // micro-kernel on the blocks below (above) the diagonal and a masked variant (through a
-// temporary) on the diagonal blocks; here the triangle is split by recursive halving: the
-// off-diagonal square of every level is ONE plain MFMA GEMM, the 256-wide diagonal leaves
-// are the guarded GEMM kernel with a row/column predicate in its epilogue, so elements
-// outside the triangle are neither read nor written.  beta is fused into those epilogues
+// temporary) on the diagonal blocks; here it is ONE launch of the MFMA GEMM over the whole of
+// C in which the workgroups of tiles outside the triangle leave at once and the tiles on the
+// diagonal write through a row/column predicate in the epilogue, so elements outside the
+// triangle are neither read nor written.  beta is fused into those epilogues
 // (the reference scales the triangle first, level3_impl.h:396-404: same result).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cstdint>
-#include <functional>
 
 #include "gemm_launch.hpp"
 #include "syrk.hpp"
@@ -22,7 +21,6 @@ namespace eigamd {
 
 namespace {
 
-constexpr int64_t kLeaf = 256;
 constexpr int kElem[4] = {4, 8, 8, 16};
 
 hipError_t launch_any(const GemmCall& c, hipStream_t s) {
@@ -67,17 +65,9 @@ hipError_t syrk_device(int kind, bool upper, int op, int64_t n, int64_t k, const
     if (beta[0] == 1.0 && beta[1] == 0.0) return hipSuccess;
     return block(0, n, 0, n, upper ? 2 : 1);   // k == 0: the launcher runs the scale kernel
   }
-  std::function<hipError_t(int64_t, int64_t)> rec = [&](int64_t r0, int64_t r1) -> hipError_t {
-    const int64_t size = r1 - r0;
-    if (size <= kLeaf) return block(r0, size, r0, size, upper ? 2 : 1);
-    const int64_t mid = r0 + (size / 2 + kLeaf - 1) / kLeaf * kLeaf;
-    hipError_t e = rec(r0, mid);
-    if (e != hipSuccess) return e;
-    e = upper ? block(r0, mid - r0, mid, r1 - mid, 0) : block(mid, r1 - mid, r0, mid - r0, 0);
-    if (e != hipSuccess) return e;
-    return rec(mid, r1);
-  };
-  return rec(0, n);
+  // One launch over the whole of C: workgroups whose tile lies outside the triangle leave at
+  // once, the tiles on the diagonal write through the row/column predicate of the epilogue.
+  return block(0, n, 0, n, upper ? 2 : 1);
 }
 
 }  // namespace eigamd
