@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Copies the summaries that tools/gpu_profile.sh left under gpurun_out/prof into profiles/
+(round tag as argument, default r01) and rewrites profiles/traffic.json from the PMC passes."""
+import json, os, re, shutil, sqlite3, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(R, "gpurun_out", "prof")
+cur = sqlite3.connect(os.path.join(src, "trace", "bench_results.db")).cursor()
+rows = cur.execute("select name, grid_x/workgroup_x, count(*), avg(end-start)/1e6, min(end-start)/1e6, max(end-start)/1e6 "
+                   "from kernels where name like '%gemm_kernel%' and (end-start) > 2e7 group by name, grid_x order by 4 desc").fetchall()
+b = json.load(open(os.path.join(src, "bench_under_trace.json")))
+with open(os.path.join(R, "profiles", f"{tag}_kernel_trace_stats_bench.txt"), "w") as f:
+    f.write("rocprofv3 --kernel-trace --stats -- python3 bench.py     (default flags: N=1, 10 steps, 2 warm-up, extras and CPU baseline on)\n")
+    f.write("summary of the rocpd database by tools/rocpd_summary.py; gemm_kernel<1,...> also counts the launches of the LU / TRSM / SYRK legs\n\n")
+    f.write(open(os.path.join(src, "kernel_trace_stats_bench.txt")).read().split("\n", 1)[1])
+    f.write("\nheadline launches only (duration > 20 ms), grouped by kernel and grid:\n")
+    f.write(" workgroups  calls     avg_ms     min_ms     max_ms  kernel\n")
+    for n, g, c, a, mn, mx in rows:
+        f.write(f" {g:10d} {c:6d} {a:10.3f} {mn:10.3f} {mx:10.3f}  {n}\n")
+    head = [r for r in rows if "gemm_kernel<1" in r[0] and r[2] >= 10]
+    if head:
+        f.write(f"\nbench.py's own HIP-event average of the timed dgemm 16384^3 launches in the same run: {b['roofline']['avg_launch_ms']} ms "
+                f"(trace: {head[0][3]:.3f} ms over {head[0][2]} launches, warm-up included); value {b['value']} TFLOP/s\n")
+json.dump(b, open(os.path.join(R, "profiles", f"{tag}_bench_n1.json"), "w"), indent=1)
+pmc = open(os.path.join(src, "pmc_gemm16384.txt")).read()
+open(os.path.join(R, "profiles", f"{tag}_pmc_gemm16384.txt"), "w").write(pmc)
+traffic = {}
+for dt in ("f64", "f32"):
+    sec = pmc.split(f"gemm_check {dt} ")[1].split("== build")[0]
+    fetch = float(re.search(r"FETCH_SIZE\s+([0-9.e+]+)", sec).group(1))
+    write = float(re.search(r"WRITE_SIZE\s+([0-9.e+]+)", sec).group(1))
+    traffic[f"{dt}_16384"] = {
+        "bytes_per_launch": float(f"{fetch * 1024 * 2 + write * 1024:.4e}"),
+        "source": f"profiles/{tag}_pmc_gemm16384.txt: FETCH_SIZE {fetch:.3e} KB x 1024 x 2 (gfx950 128-B request correction) + "
+                  f"WRITE_SIZE {write:.3e} KB x 1024; L2<->fabric traffic, Infinity-Cache hits included"}
+json.dump(traffic, open(os.path.join(R, "profiles", "traffic.json"), "w"), indent=1)
+print(json.dumps(traffic, indent=1))
