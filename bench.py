@@ -247,11 +247,25 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
+    # EIGAMD_BENCH_REHEARSAL=1: run the multi-rank code path on fewer GPUs than ranks (ranks
+    # share devices, gloo instead of RCCL, panels through a host copy).  For checking the
+    # driver logic on a one-GPU box only; its numbers mean nothing.
+    rehearsal = os.environ.get("EIGAMD_BENCH_REHEARSAL") == "1"
+    torch.cuda.set_device(local_rank % torch.cuda.device_count() if rehearsal else local_rank)
     if _lib.lib.eigamd_device_ok() != 1:
         raise SystemExit("bench.py needs an MI355X: " + _lib.lib.eigamd_last_error().decode())
+    bcast = None
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            from eigen_amd.summa import host_staged_broadcast as bcast
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
     n = args.size or (16384 if world == 1 else 65536)
     steps = args.steps if args.steps is not None else (10 if world == 1 else 3)
     warmup = args.warmup if args.warmup is not None else (2 if world == 1 else 1)
@@ -272,7 +286,7 @@ def main():
         A = DistMatrix(grid, n, n, nb, nb, kind).fill_uniform(1)
         B = DistMatrix(grid, n, n, nb, nb, kind).fill_uniform(2)
         C = DistMatrix(grid, n, n, nb, nb, kind).fill_uniform(3)
-        step = lambda: pgemm(1.0, A, B, 1.0, C, local_gemm=timed)
+        step = lambda: pgemm(1.0, A, B, 1.0, C, local_gemm=timed, broadcast=bcast)
         layout = f"2-D block-cyclic {grid.nprow}x{grid.npcol}, block {nb}, SUMMA panel broadcast over RCCL"
 
     for _ in range(warmup):
@@ -292,9 +306,7 @@ def main():
     elapsed = time.perf_counter() - t0
     timed.enabled = False
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = max_over_ranks(elapsed)
 
     # parity of what was just timed: sampled entries of C against the host
     done = warmup + steps
@@ -318,9 +330,7 @@ def main():
             return got, mask
     ratio = sampled_ratio(kind, n, getter, done)
     if world > 1:
-        t = torch.tensor([ratio], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ratio = float(t.item())
+        ratio = max_over_ranks(ratio)
 
     lu_extra = None
     if world > 1 and args.lu:
@@ -329,13 +339,12 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
-        _, _, fz = pgetrf(L)
+        _, _, fz = pgetrf(L, broadcast=bcast)
         torch.cuda.synchronize()
         dist.barrier()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        lu_extra = {f"lu_{args.lu}_f64_seconds": round(float(t.item()), 4),
-                    f"lu_{args.lu}_f64_tflops": round(2.0 / 3.0 * args.lu ** 3 / float(t.item()) / 1e12, 2),
+        lu_secs = max_over_ranks(time.perf_counter() - t0)
+        lu_extra = {f"lu_{args.lu}_f64_seconds": round(lu_secs, 4),
+                    f"lu_{args.lu}_f64_tflops": round(2.0 / 3.0 * args.lu ** 3 / lu_secs / 1e12, 2),
                     "lu_layout": f"1-D column block-cyclic over {world} GPUs, block {lu_block_size(args.lu)}"}
 
     ms, fl = timed.summary()
