@@ -74,6 +74,18 @@ for _name in ("ssyrk_", "dsyrk_", "csyrk_", "zsyrk_"):
     _f.argtypes = [ctypes.c_char_p] * 2 + [_i32p, _i32p, _vp, _vp, _i32p, _vp, _vp, _i32p]
 lib.eigamd_syrk_dev.restype = ctypes.c_int
 lib.eigamd_syrk_dev.argtypes = [ctypes.c_int] * 3 + [_i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp]
+for _name in ("ssymm_", "dsymm_", "csymm_", "zsymm_", "chemm_", "zhemm_"):
+    _f = getattr(lib, _name)
+    _f.restype = ctypes.c_int
+    _f.argtypes = [ctypes.c_char_p] * 2 + [_i32p, _i32p, _vp, _vp, _i32p, _vp, _i32p, _vp, _vp, _i32p]
+for _name in ("strmm_", "dtrmm_", "ctrmm_", "ztrmm_"):
+    _f = getattr(lib, _name)
+    _f.restype = ctypes.c_int
+    _f.argtypes = [ctypes.c_char_p] * 4 + [_i32p, _i32p, _vp, _vp, _i32p, _vp, _i32p]
+lib.eigamd_symm_dev.restype = ctypes.c_int
+lib.eigamd_symm_dev.argtypes = [ctypes.c_int] * 4 + [_i64, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp]
+lib.eigamd_trmm_dev.restype = ctypes.c_int
+lib.eigamd_trmm_dev.argtypes = [ctypes.c_int] * 5 + [_i64, _i64, _vp, _vp, _i64, _vp, _i64, _vp]
 lib.eigamd_trsm_dev.restype = ctypes.c_int
 lib.eigamd_trsm_dev.argtypes = [ctypes.c_int] * 5 + [_i64, _i64, _vp, _vp, _i64, _vp, _i64, _vp]
 lib.eigamd_last_error.restype = ctypes.c_char_p

@@ -22,6 +22,7 @@
 #include "lu.hpp"
 #include "trsm.hpp"
 #include "syrk.hpp"
+#include "level3x.hpp"
 #include "rng.hpp"
 
 using namespace eigamd;
@@ -788,6 +789,163 @@ int zsyrk_(const char* uplo, const char* trans, const int* n, const int* k, cons
            const int* lda, const double* beta, double* c, const int* ldc) {
   return f77_syrk(C64, "ZSYRK ", uplo, trans, n, k, alpha, a, lda, beta, c, ldc);
 }
+
+// ---- ?symm_ / ?hemm_ (blas/level3_impl.h:245-353, :505-560) and ?trmm_ (:183-243) -------
+
+int eigamd_symm_dev(int dtype, int side, int uplo, int hermitian, int64_t m, int64_t n, const void* alpha, const void* d_a,
+                    int64_t lda, const void* d_b, int64_t ldb, const void* beta, void* d_c, int64_t ldc, void* stream) {
+  if (dtype < 0 || dtype > 3) return fail(EIGAMD_ERR_ARG, "dtype out of range");
+  if (side < 0 || side > 1 || uplo < 0 || uplo > 1 || m < 0 || n < 0 || lda < std::max<int64_t>(1, side == 0 ? m : n) ||
+      ldb < std::max<int64_t>(1, m) || ldc < std::max<int64_t>(1, m) || m > 0x7fffffff || n > 0x7fffffff)
+    return fail(EIGAMD_ERR_ARG, "invalid symm arguments");
+  if (m == 0 || n == 0) return EIGAMD_OK;
+  int rc = ensure_device();
+  if (rc != EIGAMD_OK) return rc;
+  double al[2], be[2];
+  read_scalar(dtype, alpha, al);
+  read_scalar(dtype, beta, be);
+  HIP_TRY(symm_device(dtype, side == 0, uplo == 0, hermitian != 0 && dtype >= C32, m, n, al, d_a, lda, d_b, ldb, be, d_c, ldc,
+                      static_cast<hipStream_t>(stream)));
+  return EIGAMD_OK;
+}
+
+int eigamd_trmm_dev(int dtype, int side, int uplo, int op, int diag, int64_t m, int64_t n, const void* alpha,
+                    const void* d_a, int64_t lda, void* d_b, int64_t ldb, void* stream) {
+  if (dtype < 0 || dtype > 3) return fail(EIGAMD_ERR_ARG, "dtype out of range");
+  if (side < 0 || side > 1 || uplo < 0 || uplo > 1 || op < OP_N || op > OP_C || diag < 0 || diag > 1 || m < 0 || n < 0 ||
+      lda < std::max<int64_t>(1, side == 0 ? m : n) || ldb < std::max<int64_t>(1, m) || m > 0x7fffffff || n > 0x7fffffff)
+    return fail(EIGAMD_ERR_ARG, "invalid trmm arguments");
+  if (m == 0 || n == 0) return EIGAMD_OK;
+  int rc = ensure_device();
+  if (rc != EIGAMD_OK) return rc;
+  double al[2];
+  read_scalar(dtype, alpha, al);
+  HIP_TRY(trmm_device(dtype, side == 0, uplo == 0, op, diag == 1, m, n, al, d_a, lda, d_b, ldb,
+                      static_cast<hipStream_t>(stream)));
+  return EIGAMD_OK;
+}
+
+// Host-pointer forms: stage A (na x na), B and C / B; only the m x n window comes back.
+static int symm_host_impl(int dtype, int side, int uplo, bool herm, int64_t m, int64_t n, const double alpha[2],
+                          const void* a, int64_t lda, const void* b, int64_t ldb, const double beta[2], void* c,
+                          int64_t ldc) {
+  int rc = ensure_device();
+  if (rc != EIGAMD_OK) return rc;
+  const int es = kElemSize[dtype];
+  const int64_t na = side == 0 ? m : n;
+  const int64_t dlda = round_up(na, 16), dldb = round_up(m, 16), dldc = round_up(m, 16);
+  const bool beta_is_zero = beta[0] == 0.0 && beta[1] == 0.0;
+  Staging& st = staging();
+  std::lock_guard<std::mutex> lock(st.mu);
+  if ((rc = st.init()) != EIGAMD_OK) return rc;
+  if ((rc = st.reserve(0, (size_t)dlda * na * es)) != EIGAMD_OK) return rc;
+  if ((rc = st.reserve(1, (size_t)dldb * n * es)) != EIGAMD_OK) return rc;
+  if ((rc = st.reserve(2, (size_t)dldc * n * es)) != EIGAMD_OK) return rc;
+  if ((rc = st.upload(st.buf[0], dlda, a, lda, na, na, es)) != EIGAMD_OK) return rc;
+  if ((rc = st.upload(st.buf[1], dldb, b, ldb, m, n, es)) != EIGAMD_OK) return rc;
+  if (!beta_is_zero && (rc = st.upload(st.buf[2], dldc, c, ldc, m, n, es)) != EIGAMD_OK) return rc;
+  HIP_TRY(hipEventRecord(st.uploaded, st.h2d));
+  HIP_TRY(hipStreamWaitEvent(st.stream, st.uploaded, 0));
+  HIP_TRY(symm_device(dtype, side == 0, uplo == 0, herm, m, n, alpha, st.buf[0], dlda, st.buf[1], dldb, beta, st.buf[2], dldc,
+                      st.stream));
+  HIP_TRY(hipEventRecord(st.computed, st.stream));
+  HIP_TRY(hipStreamWaitEvent(st.d2h, st.computed, 0));
+  return st.download(c, ldc, st.buf[2], dldc, m, n, es);
+}
+
+static int f77_symm(int dtype, bool herm, const char* name, const char* side, const char* uplo, const int* m, const int* n,
+                    const void* alpha, const void* a, const int* lda, const void* b, const int* ldb, const void* beta,
+                    void* c, const int* ldc) {
+  const int sd = side_of(*side), ul = uplo_of(*uplo);
+  int info = 0;                                                    // level3_impl.h:256-266 / :517-527
+  if (sd < 0) info = 1;
+  else if (ul < 0) info = 2;
+  else if (*m < 0) info = 3;
+  else if (*n < 0) info = 4;
+  else if (*lda < std::max(1, sd == 0 ? *m : *n)) info = 7;
+  else if (*ldb < std::max(1, *m)) info = 9;
+  else if (*ldc < std::max(1, *m)) info = 12;
+  if (info) return xerbla_(name, &info, 6);
+  if (*m == 0 || *n == 0) return 0;
+  double al[2], be[2];
+  read_scalar(dtype, alpha, al);
+  read_scalar(dtype, beta, be);
+  int rc = symm_host_impl(dtype, sd, ul, herm, *m, *n, al, a, *lda, b, *ldb, be, c, *ldc);
+  if (rc != EIGAMD_OK) {
+    std::fprintf(stderr, "eigen_amd %s: %s\n", name, g_err.c_str());
+    std::abort();
+  }
+  return 0;
+}
+
+#define EIGAMD_SYMM_ENTRY(fn, T, kind, herm, name)                                                                      \
+  int fn(const char* side, const char* uplo, const int* m, const int* n, const T* alpha, const T* a, const int* lda,      \
+         const T* b, const int* ldb, const T* beta, T* c, const int* ldc) {                                               \
+    return f77_symm(kind, herm, name, side, uplo, m, n, alpha, a, lda, b, ldb, beta, c, ldc);                             \
+  }
+EIGAMD_SYMM_ENTRY(ssymm_, float, F32, false, "SSYMM ")
+EIGAMD_SYMM_ENTRY(dsymm_, double, F64, false, "DSYMM ")
+EIGAMD_SYMM_ENTRY(csymm_, float, C32, false, "CSYMM ")
+EIGAMD_SYMM_ENTRY(zsymm_, double, C64, false, "ZSYMM ")
+EIGAMD_SYMM_ENTRY(chemm_, float, C32, true, "CHEMM ")
+EIGAMD_SYMM_ENTRY(zhemm_, double, C64, true, "ZHEMM ")
+
+static int trmm_host_impl(int dtype, int side, int uplo, int op, int diag, int64_t m, int64_t n, const double alpha[2],
+                          const void* a, int64_t lda, void* b, int64_t ldb) {
+  int rc = ensure_device();
+  if (rc != EIGAMD_OK) return rc;
+  const int es = kElemSize[dtype];
+  const int64_t na = side == 0 ? m : n;
+  const int64_t dlda = round_up(na, 16), dldb = round_up(m, 16);
+  Staging& st = staging();
+  std::lock_guard<std::mutex> lock(st.mu);
+  if ((rc = st.init()) != EIGAMD_OK) return rc;
+  if ((rc = st.reserve(0, (size_t)dlda * na * es)) != EIGAMD_OK) return rc;
+  if ((rc = st.reserve(2, (size_t)dldb * n * es)) != EIGAMD_OK) return rc;
+  if ((rc = st.upload(st.buf[0], dlda, a, lda, na, na, es)) != EIGAMD_OK) return rc;
+  if ((rc = st.upload(st.buf[2], dldb, b, ldb, m, n, es)) != EIGAMD_OK) return rc;
+  HIP_TRY(hipEventRecord(st.uploaded, st.h2d));
+  HIP_TRY(hipStreamWaitEvent(st.stream, st.uploaded, 0));
+  HIP_TRY(trmm_device(dtype, side == 0, uplo == 0, op, diag == 1, m, n, alpha, st.buf[0], dlda, st.buf[2], dldb, st.stream));
+  HIP_TRY(hipEventRecord(st.computed, st.stream));
+  HIP_TRY(hipStreamWaitEvent(st.d2h, st.computed, 0));
+  return st.download(b, ldb, st.buf[2], dldb, m, n, es);
+}
+
+static int f77_trmm(int dtype, const char* name, const char* side, const char* uplo, const char* opa, const char* diag,
+                    const int* m, const int* n, const void* alpha, const void* a, const int* lda, void* b,
+                    const int* ldb) {
+  const int sd = side_of(*side), ul = uplo_of(*uplo), op = op_of(*opa), dg = diag_of(*diag);
+  int info = 0;                                                    // level3_impl.h:213-223
+  if (sd < 0) info = 1;
+  else if (ul < 0) info = 2;
+  else if (op < 0) info = 3;
+  else if (dg < 0) info = 4;
+  else if (*m < 0) info = 5;
+  else if (*n < 0) info = 6;
+  else if (*lda < std::max(1, sd == 0 ? *m : *n)) info = 9;
+  else if (*ldb < std::max(1, *m)) info = 11;
+  if (info) return xerbla_(name, &info, 6);
+  if (*m == 0 || *n == 0) return 1;                                // the reference returns 1 here (:227-228)
+  double al[2];
+  read_scalar(dtype, alpha, al);
+  int rc = trmm_host_impl(dtype, sd, ul, op, dg, *m, *n, al, a, *lda, b, *ldb);
+  if (rc != EIGAMD_OK) {
+    std::fprintf(stderr, "eigen_amd %s: %s\n", name, g_err.c_str());
+    std::abort();
+  }
+  return 1;
+}
+
+#define EIGAMD_TRMM_ENTRY(fn, T, kind, name)                                                                              \
+  int fn(const char* side, const char* uplo, const char* opa, const char* diag, const int* m, const int* n, const T* alpha, \
+         const T* a, const int* lda, T* b, const int* ldb) {                                                                \
+    return f77_trmm(kind, name, side, uplo, opa, diag, m, n, alpha, a, lda, b, ldb);                                        \
+  }
+EIGAMD_TRMM_ENTRY(strmm_, float, F32, "STRMM ")
+EIGAMD_TRMM_ENTRY(dtrmm_, double, F64, "DTRMM ")
+EIGAMD_TRMM_ENTRY(ctrmm_, float, C32, "CTRMM ")
+EIGAMD_TRMM_ENTRY(ztrmm_, double, C64, "ZTRMM ")
 
 const char* eigamd_last_error(void) { return g_err.c_str(); }
 

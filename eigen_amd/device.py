@@ -114,3 +114,26 @@ def syrk_dev(uplo, trans, alpha, a, beta, c, stream=None):
                              ctypes.c_void_p(be.ctypes.data), ctypes.c_void_p(c.ptr), c.ld, _stream_ptr(stream))
     _lib.check(rc, "eigamd_syrk_dev")
     return c
+
+
+def symm_dev(side, uplo, alpha, a, b, beta, c, hermitian=False, stream=None):
+    """c <- alpha * a * b + beta * c (side 'L') or alpha * b * a + beta * c (side 'R'), a symmetric
+    (Hermitian if asked) and read through its uplo triangle only (``eigamd_symm_dev``)."""
+    dt = _NP_OF_KIND[c.kind]
+    al, be = np.array([alpha], dtype=dt), np.array([beta], dtype=dt)
+    rc = lib.eigamd_symm_dev(c.kind, "LR".index(side.upper()), "UL".index(uplo.upper()), int(bool(hermitian)), c.rows,
+                             c.cols, ctypes.c_void_p(al.ctypes.data), ctypes.c_void_p(a.ptr), a.ld, ctypes.c_void_p(b.ptr),
+                             b.ld, ctypes.c_void_p(be.ctypes.data), ctypes.c_void_p(c.ptr), c.ld, _stream_ptr(stream))
+    _lib.check(rc, "eigamd_symm_dev")
+    return c
+
+
+def trmm_dev(side, uplo, transa, diag, alpha, a, b, stream=None):
+    """b <- alpha * op(a) * b (side 'L') or alpha * b * op(a) (side 'R'), a triangular
+    (``eigamd_trmm_dev``)."""
+    al = np.array([alpha], dtype=_NP_OF_KIND[b.kind])
+    rc = lib.eigamd_trmm_dev(b.kind, "LR".index(side.upper()), "UL".index(uplo.upper()), _OPCODE[transa.upper()],
+                             "NU".index(diag.upper()), b.rows, b.cols, ctypes.c_void_p(al.ctypes.data),
+                             ctypes.c_void_p(a.ptr), a.ld, ctypes.c_void_p(b.ptr), b.ld, _stream_ptr(stream))
+    _lib.check(rc, "eigamd_trmm_dev")
+    return b

@@ -171,6 +171,42 @@ int zsyrk_(const char* uplo, const char* trans, const int* n, const int* k, cons
 int eigamd_syrk_dev(int dtype, int uplo, int op, int64_t n, int64_t k, const void* alpha, const void* d_a, int64_t lda,
                     const void* beta, void* d_c, int64_t ldc, void* stream);
 
+/* ---- products with a symmetric / Hermitian / triangular operand ------------------
+ *
+ * {s,d,c,z}symm_ and {c,z}hemm_ replace EIGEN_BLAS_FUNC(symm) / (hemm)
+ * (blas/level3_impl.h:245-353, :505-560): C <- alpha A B + beta C (side 'L') or
+ * alpha B A + beta C (side 'R'), A symmetric (Hermitian for ?hemm_: the imaginary part of its
+ * diagonal is ignored), only the uplo triangle of A is read.  xerbla_ codes 1 side, 2 uplo,
+ * 3 m, 4 n, 7 lda, 9 ldb, 12 ldc.
+ * {s,d,c,z}trmm_ replace EIGEN_BLAS_FUNC(trmm) (:183-243): B <- alpha op(A) B (side 'L') or
+ * alpha B op(A) (side 'R'), A triangular; codes as ?trsm_.
+ * Under EIGEN_USE_BLAS they are what SelfadjointMatrixMatrix_BLAS.h and
+ * TriangularMatrixMatrix_BLAS.h bind.  The *_dev forms take matrices already in HBM. */
+int ssymm_(const char* side, const char* uplo, const int* m, const int* n, const float* alpha, const float* a, const int* lda,
+           const float* b, const int* ldb, const float* beta, float* c, const int* ldc);
+int dsymm_(const char* side, const char* uplo, const int* m, const int* n, const double* alpha, const double* a,
+           const int* lda, const double* b, const int* ldb, const double* beta, double* c, const int* ldc);
+int csymm_(const char* side, const char* uplo, const int* m, const int* n, const float* alpha, const float* a, const int* lda,
+           const float* b, const int* ldb, const float* beta, float* c, const int* ldc);
+int zsymm_(const char* side, const char* uplo, const int* m, const int* n, const double* alpha, const double* a,
+           const int* lda, const double* b, const int* ldb, const double* beta, double* c, const int* ldc);
+int chemm_(const char* side, const char* uplo, const int* m, const int* n, const float* alpha, const float* a, const int* lda,
+           const float* b, const int* ldb, const float* beta, float* c, const int* ldc);
+int zhemm_(const char* side, const char* uplo, const int* m, const int* n, const double* alpha, const double* a,
+           const int* lda, const double* b, const int* ldb, const double* beta, double* c, const int* ldc);
+int strmm_(const char* side, const char* uplo, const char* transa, const char* diag, const int* m, const int* n,
+           const float* alpha, const float* a, const int* lda, float* b, const int* ldb);
+int dtrmm_(const char* side, const char* uplo, const char* transa, const char* diag, const int* m, const int* n,
+           const double* alpha, const double* a, const int* lda, double* b, const int* ldb);
+int ctrmm_(const char* side, const char* uplo, const char* transa, const char* diag, const int* m, const int* n,
+           const float* alpha, const float* a, const int* lda, float* b, const int* ldb);
+int ztrmm_(const char* side, const char* uplo, const char* transa, const char* diag, const int* m, const int* n,
+           const double* alpha, const double* a, const int* lda, double* b, const int* ldb);
+int eigamd_symm_dev(int dtype, int side, int uplo, int hermitian, int64_t m, int64_t n, const void* alpha, const void* d_a,
+                    int64_t lda, const void* d_b, int64_t ldb, const void* beta, void* d_c, int64_t ldc, void* stream);
+int eigamd_trmm_dev(int dtype, int side, int uplo, int op, int diag, int64_t m, int64_t n, const void* alpha,
+                    const void* d_a, int64_t lda, void* d_b, int64_t ldb, void* stream);
+
 /* ---- misc --------------------------------------------------------------------- */
 const char* eigamd_last_error(void);  /* text of the last failure on this thread */
 int eigamd_device_ok(void);           /* 1 if a gfx950 device is usable, else 0 */

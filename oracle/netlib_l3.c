@@ -24,6 +24,9 @@ typedef int (*trsm_fn_t)(const char *, const char *, const char *, const char *,
 typedef int (*syrk_fn_t)(const char *, const char *, const int *, const int *, const void *, const void *, const int *,
                          const void *, void *, const int *);
 
+typedef int (*symm_fn_t)(const char *, const char *, const int *, const int *, const void *, const void *, const int *,
+                         const void *, const int *, const void *, void *, const int *);
+
 struct netlib_report {
   int ncalls;        /* calls made by ?CHK1 */
   int nfail_same;    /* an argument or C's padding came back changed */

@@ -1,5 +1,6 @@
-/* CPU oracle for the triangular solve with many right-hand sides (?trsm_) and the symmetric
- * rank-k update (?syrk_): plain C, float, double, complex float, complex double, every form.
+/* CPU oracle for the triangular solve with many right-hand sides (?trsm_), the symmetric
+ * rank-k update (?syrk_) and the products with a symmetric / Hermitian / triangular operand
+ * (?symm_, ?hemm_, ?trmm_): plain C, float, double, complex float, complex double, every form.
  *
  * TEST INFRASTRUCTURE ONLY.  Callers: tests/.  The product library never links this file.
  *
@@ -62,8 +63,10 @@ extern int xerbla_(const char *msg, int *info, int len);
 #define SFX c
 #define IS_CPLX 1
 #define CONJ(x) conjf(x)
+#define CREAL_(x) ((float _Complex)crealf(x))
 #define LETTER 'C'
 #include "trsm_oracle_impl.inc"
+#undef CREAL_
 #undef SCALAR
 #undef REAL
 #undef SFX
@@ -76,5 +79,6 @@ extern int xerbla_(const char *msg, int *info, int len);
 #define SFX z
 #define IS_CPLX 1
 #define CONJ(x) conj(x)
+#define CREAL_(x) ((double _Complex)creal(x))
 #define LETTER 'Z'
 #include "trsm_oracle_impl.inc"

@@ -280,6 +280,68 @@ def syrk_operands(kind, uplo, trans, n, k, seed, pad=0):
     return a, c
 
 
+def run_netlib_chk2(kind, fn, herm, params):
+    """Restated ?CHK2 (SYMM; HEMM when herm) over `fn` (ctypes function, ?symm_ signature)."""
+    real = ctypes.c_float if kind in (0, 2) else ctypes.c_double
+    idim = (ctypes.c_int * len(params["idim"]))(*params["idim"])
+    alf = (real * len(params["alf"]))(*params["alf"])
+    bet = (real * len(params["bet"]))(*params["bet"])
+    per = 2 if params["cplx"] else 1
+    rep = NetlibReport()
+    f = getattr(oracle, "netlib_chk2_" + SUFFIX[kind])
+    f(ctypes.cast(fn, ctypes.c_void_p), int(herm), len(params["idim"]), idim, len(params["alf"]) // per, alf,
+      len(params["bet"]) // per, bet, ctypes.byref(rep))
+    return rep
+
+
+def run_netlib_chk3_trmm(kind, fn, params):
+    """Restated TRMM rows of ?CHK3 over `fn` (ctypes function, ?trmm_ signature)."""
+    real = ctypes.c_float if kind in (0, 2) else ctypes.c_double
+    idim = (ctypes.c_int * len(params["idim"]))(*params["idim"])
+    alf = (real * len(params["alf"]))(*params["alf"])
+    per = 2 if params["cplx"] else 1
+    rep = NetlibReport()
+    f = getattr(oracle, "netlib_chk3_trmm_" + SUFFIX[kind])
+    f(ctypes.cast(fn, ctypes.c_void_p), len(params["idim"]), idim, len(params["alf"]) // per, alf, ctypes.byref(rep))
+    return rep
+
+
+def call_f77_symm(fn, side, uplo, m, n, alpha, a, lda, b, ldb, beta, c, ldc):
+    """Call any function with the F77 ?symm_ / ?hemm_ signature on numpy buffers (c is updated)."""
+    al, be = np.array([alpha], dtype=c.dtype), np.array([beta], dtype=c.dtype)
+    ci = lambda v: ctypes.byref(ctypes.c_int(int(v)))
+    cs = lambda ch: ctypes.c_char_p(ch.encode())
+    fn(cs(side), cs(uplo), ci(m), ci(n), _vp(al), _vp(a), ci(lda), _vp(b), ci(ldb), _vp(be), _vp(c), ci(ldc))
+    return c
+
+
+def symm_operands(kind, side, uplo, herm, m, n, seed, pad=0):
+    """A (na x na, the uplo triangle meaningful, -1e10 in the other one and, for a Hermitian A,
+    in the imaginary part of the diagonal), B and C (m x n)."""
+    import eigen_amd
+    dt = DTYPES[kind]
+    na = m if side == "L" else n
+    a = eigen_amd.fill_uniform_host(dt, na, na, seed, ld=na + pad)
+    b = eigen_amd.fill_uniform_host(dt, m, n, seed + 1, ld=m + pad)
+    c = eigen_amd.fill_uniform_host(dt, m, n, seed + 2, ld=m + pad)
+    if na:
+        i, j = np.indices((na, na))
+        a[(i > j) if uplo == "U" else (i < j)] = -1.0e10
+        if herm:
+            a[i == j] = a[i == j].real - 1.0e10j
+    return a, b, c
+
+
+def dense_symmetric(a, uplo, herm):
+    """The full symmetric / Hermitian matrix stored in one triangle of a."""
+    t = np.triu(a) if uplo == "U" else np.tril(a)
+    d = np.diag(np.diagonal(t))
+    off = t - d
+    if herm:
+        return off + off.conj().T + d.real
+    return off + off.T + d
+
+
 def gauge_ratio(kind, got, ref, alpha, a_abs1, b_abs1, beta, c0, k):
     """Componentwise ?MMCH-style ratio |got - ref| / (eps * G) with
     G = abs1(alpha) * (|A| |B|)_ij + abs1(beta) * abs1(c0_ij)."""
