@@ -77,6 +77,60 @@ template <typename S> static void product_cases(const char* tag, double tol) {
   expect_close(name, big, ref, tol);
 }
 
+#ifdef EIGEN_USE_BLAS
+// The other level-3 routines the reference's headers bind under EIGEN_USE_BLAS
+// (TriangularSolverMatrix_BLAS.h, TriangularMatrixMatrix_BLAS.h, SelfadjointMatrixMatrix_BLAS.h,
+// GeneralMatrixMatrixTriangular_BLAS.h): ?trsm_, ?trmm_, ?symm_ / ?hemm_, ?syrk_ resolve in our library.
+template <typename S> static void structured_cases(const char* tag, double tol) {
+  typedef Matrix<S, Dynamic, Dynamic> Mat;
+  char name[96];
+  const int n = 230, m = 120;
+  // off-diagonal entries small against the diagonal (also against a unit diagonal), real
+  // diagonal (a self-adjoint view ignores its imaginary part, a dense copy would not)
+  Mat a = Mat::Random(n, n) * S(4.0 / n);
+  a.diagonal() = (a.diagonal().real().array() + 2.0).matrix().template cast<S>();
+  const Mat b = Mat::Random(n, m), br = Mat::Random(m, n);
+
+  Mat x = b;
+  a.template triangularView<Lower>().solveInPlace(x);
+  std::snprintf(name, sizeof name, "%s tri<Lower>.solveInPlace(B)", tag);
+  expect_close(name, Mat(a.template triangularView<Lower>()).lazyProduct(x).eval(), b, 50 * tol);
+
+  x = br;
+  a.template triangularView<UnitUpper>().template solveInPlace<OnTheRight>(x);
+  std::snprintf(name, sizeof name, "%s tri<UnitUpper>.solveInPlace<OnTheRight>(B)", tag);
+  expect_close(name, x.lazyProduct(Mat(a.template triangularView<UnitUpper>())).eval(), br, 50 * tol);
+
+  x = b;
+  a.adjoint().template triangularView<Lower>().solveInPlace(x);
+  std::snprintf(name, sizeof name, "%s A^H tri<Lower>.solveInPlace(B)", tag);
+  expect_close(name, Mat(a.adjoint().template triangularView<Lower>()).lazyProduct(x).eval(), b, 50 * tol);
+
+  Mat c = a.template triangularView<Upper>() * b;
+  std::snprintf(name, sizeof name, "%s C = tri<Upper>(A)*B", tag);
+  expect_close(name, c, Mat(a.template triangularView<Upper>()).lazyProduct(b).eval(), tol);
+
+  c = br * a.template triangularView<UnitLower>();
+  std::snprintf(name, sizeof name, "%s C = B*tri<UnitLower>(A)", tag);
+  expect_close(name, c, br.lazyProduct(Mat(a.template triangularView<UnitLower>())).eval(), tol);
+
+  c = a.template selfadjointView<Lower>() * b;
+  std::snprintf(name, sizeof name, "%s C = selfadjoint<Lower>(A)*B", tag);
+  expect_close(name, c, Mat(a.template selfadjointView<Lower>()).lazyProduct(b).eval(), tol);
+
+  c = br * a.template selfadjointView<Upper>();
+  std::snprintf(name, sizeof name, "%s C = B*selfadjoint<Upper>(A)", tag);
+  expect_close(name, c, br.lazyProduct(Mat(a.template selfadjointView<Upper>())).eval(), tol);
+
+  Mat s0 = Mat::Random(n, n), s1 = s0;
+  s1.template selfadjointView<Lower>().rankUpdate(b, S(2));
+  Mat want = s0;
+  want.template triangularView<Lower>() += (S(2) * b.lazyProduct(b.adjoint())).eval();
+  std::snprintf(name, sizeof name, "%s selfadjoint<Lower>.rankUpdate(B, 2)", tag);
+  expect_close(name, s1, want, tol);
+}
+#endif
+
 static void lu_case(int n) {
   MatrixXd m1 = MatrixXd::Random(n, n);
   PartialPivLU<MatrixXd> plu(m1);
@@ -105,6 +159,12 @@ int main(int argc, char** argv) {
   product_cases<double>("double", 1e-13);
   product_cases<std::complex<float> >("cfloat", 2e-5);
   product_cases<std::complex<double> >("cdouble", 1e-13);
+#ifdef EIGEN_USE_BLAS
+  structured_cases<float>("float", 2e-5);
+  structured_cases<double>("double", 1e-13);
+  structured_cases<std::complex<float> >("cfloat", 2e-5);
+  structured_cases<std::complex<double> >("cdouble", 1e-13);
+#endif
   lu_case(100);
   lu_case(1024);
   std::printf("%s (%d failures)\n", g_fail ? "DROPIN FAIL" : "DROPIN PASS", g_fail);
