@@ -486,8 +486,7 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
   for (; t < ntiles; ++t) tile(t, std::false_type{});
 
   // Epilogue: C = alpha * acc + beta * C.  beta == 0 never reads C
-  // (blas/level3_impl.h:64: NaN/Inf in C must not propagate).  Per column group j the
-  // loads of C are issued together, then combined and stored.
+  // (blas/level3_impl.h:64: NaN/Inf in C must not propagate).
   const bool use_c = p.beta[0] != 0.0 || p.beta[1] != 0.0;
   // Triangular destinations (the symmetric rank-k update): elements outside the triangle are
   // neither read nor written; only the epilogue knows about it.
@@ -500,36 +499,43 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
   const Real alr = (Real)p.alpha[0], ali = (Real)p.alpha[1];
   const Real ber = (Real)p.beta[0], bei = (Real)p.beta[1];
   const Real sgn = p.conj_a ? (Real)-1 : (Real)1;
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    Elem cv[MT][T::NACC];
-    if (use_c) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int r = 0; r < T::NACC; ++r) {
-          const int nn = j * TM + acc_row<KIND>(r, 0);
-          Elem z = {};
-          cv[i][r] = ((!GUARD || (mrow + i * TM < mrem && nrow + nn < nrem)) && in_tri(m0 + mrow + i * TM, n0 + nrow + nn))
-                         ? cbase[i * TM + (int64_t)nn * p.ldc] : z;
-        }
-    }
+  // Where the registers allow it (one column group of C = 32 VGPRs: f64), the loads of column
+  // group j+1 are in flight while group j is combined and stored.
+  constexpr int kEpiStages = (MT * T::NACC * (int)sizeof(Elem) / 4 <= 32) ? 2 : 1;
+  Elem cv[kEpiStages][MT][T::NACC];
+  auto load_group = [&](int j, Elem (&dst)[MT][T::NACC]) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int r = 0; r < T::NACC; ++r) {
         const int nn = j * TM + acc_row<KIND>(r, 0);
+        Elem z = {};
+        dst[i][r] = ((!GUARD || (mrow + i * TM < mrem && nrow + nn < nrem)) && in_tri(m0 + mrow + i * TM, n0 + nrow + nn))
+                        ? cbase[i * TM + (int64_t)nn * p.ldc] : z;
+      }
+  };
+  if (use_c && kEpiStages == 2) load_group(0, cv[0]);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    if (use_c && kEpiStages == 1) load_group(j, cv[0]);
+    if (use_c && kEpiStages == 2 && j + 1 < NT) load_group(j + 1, cv[(j + 1) % kEpiStages]);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < T::NACC; ++r) {
+        const int nn = j * TM + acc_row<KIND>(r, 0);
+        const Elem cin = cv[j % kEpiStages][i][r];
         Elem v;
         if constexpr (!T::kCplx) {
           v = alr * acc[j][i][0][r];
-          if (use_c) v = fma(ber, cv[i][r], v);
+          if (use_c) v = fma(ber, cin, v);
         } else {
           const Real pr = acc[j][i][0][r], pi = sgn * acc[j][i][1][r];
           v.x = alr * pr - ali * pi;
           v.y = alr * pi + ali * pr;
           if (use_c) {
-            v.x += ber * cv[i][r].x - bei * cv[i][r].y;
-            v.y += ber * cv[i][r].y + bei * cv[i][r].x;
+            v.x += ber * cin.x - bei * cin.y;
+            v.y += ber * cin.y + bei * cin.x;
           }
         }
         if ((!GUARD || (mrow + i * TM < mrem && nrow + nn < nrem)) && in_tri(m0 + mrow + i * TM, n0 + nrow + nn))
