@@ -197,6 +197,26 @@ def syrk_measurement(n):
     return {f"dsyrk_ln_{n}_tflops": round(float(n) ** 3 / best / 1e9, 2)}
 
 
+def trmm_measurement(n):
+    """dtrmm('L','L','N','N') with an n x n triangle and n columns resident in HBM
+    (eigamd_trmm_dev); n^3 flop (the useful half of the dense product)."""
+    import torch
+    import eigen_amd
+    from eigen_amd.device import DeviceMatrix, trmm_dev
+    a = DeviceMatrix(n, n, eigen_amd.F64).fill_uniform(9)
+    b = DeviceMatrix(n, n, eigen_amd.F64)
+    best = 1e30
+    for _ in range(3):
+        b.fill_uniform(10)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        trmm_dev("L", "L", "N", "N", 1.0, a, b)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return {f"dtrmm_llnn_{n}_tflops": round(float(n) ** 3 / best / 1e9, 2)}
+
+
 def lu_measurement(n):
     """PartialPivLU-equivalent factorisation (eigamd_getrf_dev) of an n x n double matrix
     resident in HBM; 2/3 n^3 flop.  The trailing updates run on the GEMM kernel."""
@@ -392,6 +412,7 @@ def main():
                 out["extra"].update(lu_measurement(32768))
                 out["extra"].update(trsm_measurement(16384))
                 out["extra"].update(syrk_measurement(16384))
+                out["extra"].update(trmm_measurement(16384))
                 out["extra"]["sgemm_pct_of_peak"] = round(100 * out["extra"]["sgemm_16384_tflops"] / PEAK_TFLOPS["f32"], 2)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args)

@@ -48,6 +48,9 @@ struct GemmParams {
   int xcd_remap;          // 1: give each XCD a contiguous run of the tile sequence
   int tri;                // 0 all of C, 1 only row >= col, 2 only row <= col (indices of the whole C:
   int tri_r0, tri_c0;     // this launch covers the region that starts at row tri_r0, column tri_c0)
+  int ktri;               // structural zeros of a triangular operand: terms of the reduction known to
+                          // vanish are skipped by whole k-tiles.  0 none; op(A)(row, k) = 0 for 1: k > row,
+                          // 2: k < row; op(B)(k, col) = 0 for 3: k > col, 4: k < col
 };
 
 // Tile geometry per scalar kind.  WM x WN wavefronts per workgroup, each owning
@@ -334,7 +337,16 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
     mask_i = same ? 0u : 0x80000000u;
   }
 
-  const int ntiles = (p.K + BK - 1) / BK;
+  // k-tiles [t_begin, t_end) of this workgroup: all of them, or fewer when an operand is
+  // triangular (the skipped tiles hold zeros only; tiles that straddle the diagonal are read,
+  // their zeros are in memory).
+  int t_begin = 0, t_end = (p.K + BK - 1) / BK;
+  if (p.ktri == 1) t_end = min(t_end, (p.tri_r0 + m0 + BM - 1) / BK + 1);
+  if (p.ktri == 2) t_begin = (p.tri_r0 + m0) / BK;
+  if (p.ktri == 3) t_end = min(t_end, (p.tri_c0 + n0 + BN - 1) / BK + 1);
+  if (p.ktri == 4) t_begin = (p.tri_c0 + n0) / BK;
+  pa += (int64_t)t_begin * stepa;
+  pb += (int64_t)t_begin * stepb;
   constexpr int KSTEPS = BK / KS;
   constexpr int NA = IOA::NCHUNK, NB = IOB::NCHUNK, NCH = NA + NB;
   constexpr bool PIPE = T::S::PIPE;
@@ -380,11 +392,11 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
     pb += stepb;
   };
 
-  if (ntiles > 0) {
-    load_tile(0);
+  if (t_begin < t_end) {
+    load_tile(t_begin);
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) store_chunk(c, smem);
-    if (PIPE && ntiles > 1) load_tile(1);
+    for (int c = 0; c < NCH; ++c) store_chunk(c, smem + (t_begin & 1) * (LDS_A + LDS_B));
+    if (PIPE && t_begin + 1 < t_end) load_tile(t_begin + 1);
   }
   __syncthreads();
 
@@ -400,8 +412,8 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
     const Elem* sb = smem + (t & 1) * (LDS_A + LDS_B) + LDS_A + fb0;
     Elem* next_stage = smem + ((t + 1) & 1) * (LDS_A + LDS_B);
     const int krem = p.K - (t + LEAD) * BK;
-    const bool do_store = (STEADY || t + 1 < ntiles) && !(EIGAMD_ABLATE & 2);
-    const bool do_load = (STEADY || t + LEAD < ntiles) && !(EIGAMD_ABLATE & 1);
+    const bool do_store = (STEADY || t + 1 < t_end) && !(EIGAMD_ABLATE & 2);
+    const bool do_load = (STEADY || t + LEAD < t_end) && !(EIGAMD_ABLATE & 1);
     const bool guard = !STEADY && (GUARD || krem < BK);
     // In the interleaved pipeline the position of the copies among the MFMAs is the
     // point, so the instruction scheduler may not move anything across a used slot.
@@ -478,12 +490,12 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
     if (!(EIGAMD_ABLATE & 4)) __syncthreads();
   };
 
-  int t = 0;
+  int t = t_begin;
   if constexpr (!GUARD) {
-    const int nfull = p.K / BK;
+    const int nfull = min(p.K / BK, t_end);
     for (; t + LEAD < nfull; ++t) tile(t, std::true_type{});
   }
-  for (; t < ntiles; ++t) tile(t, std::false_type{});
+  for (; t < t_end; ++t) tile(t, std::false_type{});
 
   // Epilogue: C = alpha * acc + beta * C.  beta == 0 never reads C
   // (blas/level3_impl.h:64: NaN/Inf in C must not propagate).

@@ -22,6 +22,7 @@ struct GemmCall {
   const void* B; int64_t ldb;
   void* C; int64_t ldc;
   int tri = 0;  // 1 / 2: write (and read) only the lower / upper triangle of C (row >= col / row <= col)
+  int ktri = 0; // structural zeros of a triangular operand (GemmParams::ktri)
 };
 
 // Block-to-tile mapping knobs; the defaults are what the shipped library uses, the
@@ -69,10 +70,12 @@ static hipError_t launch_region(const GemmCall& c, int64_t r0, int64_t c0, int64
   p.conj_a = (c.opa == OP_C || c.opa == OP_CONJ);
   p.conj_b = (c.opb == OP_C || c.opb == OP_CONJ);
   p.group_m = tuning().group_m;
-  // A triangular destination leaves about half of the tiles empty: contiguous runs of the tile
-  // sequence per XCD would give the XCDs very different amounts of work, round-robin does not.
-  p.xcd_remap = c.tri ? 0 : tuning().xcd_remap;
+  // A triangular destination leaves about half of the tiles empty, a triangular operand gives
+  // the tiles very different reduction lengths: contiguous runs of the tile sequence per XCD
+  // would give the XCDs very different amounts of work, round-robin does not.
+  p.xcd_remap = (c.tri || c.ktri) ? 0 : tuning().xcd_remap;
   p.tri = c.tri; p.tri_r0 = (int)r0; p.tri_c0 = (int)c0;
+  p.ktri = c.ktri;
   const int64_t nblk = (int64_t)p.tiles_m * p.tiles_n;
   if (nblk > 0x7fffffff) return hipErrorInvalidValue;
   hipLaunchKernelGGL((gemm_kernel<KIND, AK, BKC, GUARD>), dim3((unsigned)nblk), dim3(G::THREADS),

@@ -8,7 +8,7 @@
 // its BLAS wrapper itself goes through dense temporaries for the complex symmetric case
 // (:308-322) and for B in trmm (:229-231).  Here the special operand is expanded once into a
 // dense matrix in HBM by a small kernel (O(n^2) bytes against O(n^2 m) flop) and the product is
-// the MFMA GEMM; trmm multiplies the structural zeros too.
+// the MFMA GEMM; for trmm the kernel skips the k-tiles that hold structural zeros only.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -174,8 +174,9 @@ hipError_t trmm_device(int kind, bool left, bool upper, int op, bool unit, int64
   g.m = m; g.n = n; g.k = na;
   g.alpha[0] = alpha[0]; g.alpha[1] = alpha[1];
   g.beta[0] = 0.0; g.beta[1] = 0.0;
-  if (left) { g.opa = op; g.A = X; g.lda = ldx; g.opb = OP_N; g.B = Y; g.ldb = ldy; }
-  else      { g.opa = OP_N; g.A = Y; g.lda = ldy; g.opb = op; g.B = X; g.ldb = ldx; }
+  const bool eff_lower = (!upper) == (op == OP_N);  // op(A) is lower triangular
+  if (left) { g.opa = op; g.A = X; g.lda = ldx; g.opb = OP_N; g.B = Y; g.ldb = ldy; g.ktri = eff_lower ? 1 : 2; }
+  else      { g.opa = OP_N; g.A = Y; g.lda = ldy; g.opb = op; g.B = X; g.ldb = ldx; g.ktri = eff_lower ? 4 : 3; }
   g.C = B; g.ldc = ldb;
   LX_TRY(launch_any(g, s));
   return hipEventRecord(sc.done, s);
