@@ -454,6 +454,51 @@ __global__ void lu_laswp(T* __restrict__ A, int64_t ld, int ncols, const int* __
   }
 }
 
+// C (rows x cols) -= A (rows x jb) * B (jb x cols), jb <= 16: the update of the rest of a
+// panel after one base case (PartialPivLU.h:494 at the inner level).  Two flops per 16 bytes
+// of C: a streaming kernel -- thread = one row of A in registers, a 64-column slab of B in
+// LDS -- in ONE launch, where the GEMM kernel needs an interior launch and edge strips.
+constexpr int kRankCols = 64;
+template <typename T>
+__global__ void __launch_bounds__(256) lu_rank_update(const T* __restrict__ A, const T* __restrict__ B, T* __restrict__ C,
+                                                      int64_t ld, int rows, int cols, int jb) {
+  __shared__ T s_b[kMaxBase][kRankCols];
+  const int c0 = blockIdx.y * kRankCols;
+  const int nc = min(kRankCols, cols - c0);
+  for (int idx = threadIdx.x; idx < kMaxBase * kRankCols; idx += 256) {
+    const int k = idx / kRankCols, j = idx % kRankCols;
+    s_b[k][j] = (k < jb && j < nc) ? B[k + (int64_t)(c0 + j) * ld] : (T)0;
+  }
+  __syncthreads();
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  T a[kMaxBase];
+#pragma unroll
+  for (int k = 0; k < kMaxBase; ++k) a[k] = k < jb ? A[r + (int64_t)k * ld] : (T)0;
+  T* Cr = C + r + (int64_t)c0 * ld;
+  int j0 = 0;
+  for (; j0 + 8 <= nc; j0 += 8) {   // whole groups of 8 columns: independent loads, no tests
+    T c[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c[u] = Cr[(int64_t)(j0 + u) * ld];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      T acc = (T)0;
+#pragma unroll
+      for (int k = 0; k < kMaxBase; ++k) acc += a[k] * s_b[k][j0 + u];
+      c[u] -= acc;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) Cr[(int64_t)(j0 + u) * ld] = c[u];
+  }
+  for (; j0 < nc; ++j0) {
+    T acc = (T)0;
+#pragma unroll
+    for (int k = 0; k < kMaxBase; ++k) acc += a[k] * s_b[k][j0];
+    Cr[(int64_t)j0 * ld] -= acc;
+  }
+}
+
 // ---- many transpositions at once ----------------------------------------------------
 //
 // A run of transpositions i <-> transp[i], i in [k0, k1), k1 - k0 <= kPlanSpan, applied in
@@ -818,7 +863,7 @@ hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows
     LU_TRY(blocked<T>(base, ld, row0 + k, col0 + k, trows + bs, bs, transp, 16, w, s));
     if (bs <= kMaxBase) {
       // Narrow blocks (inside a panel): the transpositions on both sides (A_0 :479-483, A_2
-      // :488-489) and the triangular solve (:492) in one launch, then the GEMM (:494).
+      // :488-489) and the triangular solve (:492) in one launch, then the rank-bs update (:494).
       const int64_t nright = trows ? tsize : 0;
       if (k + nright > 0) {
         hipLaunchKernelGGL(lu_rowops<T>, dim3((unsigned)((k + nright + 63) / 64)), dim3(64), 0, s, base + col0 * ld, (int)k,
@@ -826,9 +871,12 @@ hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows
                            A + k + k * ld, (int)bs);
         LU_TRY(hipGetLastError());
       }
-      if (trows)
-        LU_TRY(gemm_minus<T>(trows, tsize, bs, A + (k + bs) + k * ld, A + k + (k + bs) * ld,
-                             A + (k + bs) + (k + bs) * ld, ld, s));
+      if (trows && tsize > 0) {
+        hipLaunchKernelGGL(lu_rank_update<T>, dim3((unsigned)((trows + 255) / 256), (unsigned)((tsize + kRankCols - 1) / kRankCols)),
+                           dim3(256), 0, s, A + (k + bs) + k * ld, A + k + (k + bs) * ld, A + (k + bs) + (k + bs) * ld, ld,
+                           (int)trows, (int)tsize, (int)bs);
+        LU_TRY(hipGetLastError());
+      }
       continue;
     }
     // transpositions of the panel on the columns to its left inside this level (A_0, :479-483)
