@@ -217,6 +217,28 @@ def trmm_measurement(n):
     return {f"dtrmm_llnn_{n}_tflops": round(float(n) ** 3 / best / 1e9, 2)}
 
 
+def mixed_measurement(n):
+    """Complex-double A times real-double B (eigamd_gemm_mixed_dev), C += A*B resident in HBM:
+    4 n^3 flop (a complex x real multiply-add is 2 multiplications and 2 additions).  With a
+    plain A and real alpha it is one launch of the real kernel on the (re, im)-interleaved rows."""
+    import torch
+    import eigen_amd
+    from eigen_amd.device import DeviceMatrix, gemm_mixed_dev
+    a = DeviceMatrix(n, n, eigen_amd.C64).fill_uniform(11)
+    b = DeviceMatrix(n, n, eigen_amd.F64).fill_uniform(12)
+    c = DeviceMatrix(n, n, eigen_amd.C64).fill_uniform(13)
+    gemm_mixed_dev("N", "N", 1.0, a, b, 1.0, c)
+    best = 1e30
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        gemm_mixed_dev("N", "N", 1.0, a, b, 1.0, c)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return {f"zgemm_complex_x_real_{n}_tflops": round(4.0 * float(n) ** 3 / best / 1e9, 2)}
+
+
 def lu_measurement(n):
     """PartialPivLU-equivalent factorisation (eigamd_getrf_dev) of an n x n double matrix
     resident in HBM; 2/3 n^3 flop.  The trailing updates run on the GEMM kernel."""
@@ -413,6 +435,7 @@ def main():
                 out["extra"].update(trsm_measurement(16384))
                 out["extra"].update(syrk_measurement(16384))
                 out["extra"].update(trmm_measurement(16384))
+                out["extra"].update(mixed_measurement(8192))
                 out["extra"]["sgemm_pct_of_peak"] = round(100 * out["extra"]["sgemm_16384_tflops"] / PEAK_TFLOPS["f32"], 2)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args)

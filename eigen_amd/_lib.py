@@ -44,6 +44,10 @@ lib.eigamd_gemm_host.restype = ctypes.c_int
 lib.eigamd_gemm_host.argtypes = [ctypes.c_int] * 3 + [_i64] * 3 + [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64]
 lib.eigamd_gemm_dev.restype = ctypes.c_int
 lib.eigamd_gemm_dev.argtypes = [ctypes.c_int] * 3 + [_i64] * 3 + [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp]
+lib.eigamd_gemm_ex_host.restype = ctypes.c_int
+lib.eigamd_gemm_ex_host.argtypes = [ctypes.c_int] * 5 + [_i64] * 3 + [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64]
+lib.eigamd_gemm_mixed_dev.restype = ctypes.c_int
+lib.eigamd_gemm_mixed_dev.argtypes = [ctypes.c_int] * 5 + [_i64] * 3 + [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp]
 lib.eigamd_fill_uniform_dev.restype = ctypes.c_int
 lib.eigamd_fill_uniform_dev.argtypes = [ctypes.c_int, _vp, _i64, _i64, _i64, ctypes.c_uint64, _vp]
 lib.eigamd_fill_uniform_cyclic_dev.restype = ctypes.c_int

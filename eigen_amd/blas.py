@@ -70,6 +70,21 @@ def gemm_host(opa, opb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc):
     return c
 
 
+def gemm_ex_host(opa, opb, m, n, k, alpha, a, lda, b, ldb, beta, c, c_inc, ldc):
+    """``eigamd_gemm_ex_host``: the product with a destination whose rows lie ``c_inc``
+    elements apart and / or with one operand of real scalars beside a complex one (which
+    operand is real is read off the dtypes of ``a`` and ``b``; the kind is that of ``c``)."""
+    kind = KIND_OF_DTYPE[c.dtype]
+    a_real = int(a.dtype.kind == "f" and c.dtype.kind == "c")
+    b_real = int(b.dtype.kind == "f" and c.dtype.kind == "c")
+    al = np.array([alpha], dtype=c.dtype)
+    be = np.array([beta], dtype=c.dtype)
+    rc = lib.eigamd_gemm_ex_host(kind, a_real, b_real, _OPCODE[opa], _OPCODE[opb], m, n, k, _ptr(al), _ptr(a), lda,
+                                 _ptr(b), ldb, _ptr(be), _ptr(c), c_inc, ldc)
+    _lib.check(rc, "eigamd_gemm_ex_host")
+    return c
+
+
 def fill_uniform_host(dtype, rows, cols, seed, ld=None):
     """Column-major rows x cols matrix of U[-1,1) entries from the library's
     counter-based generator (bit-identical to ``eigamd_fill_uniform_dev``).  Returns a

@@ -224,10 +224,13 @@ struct Staging {
 
   // rows x cols elements of `es` bytes from host (leading dimension ld) to device (dld),
   // through the pinned chunks, asynchronously on the h2d stream.
-  int upload(void* dev, int64_t dld, const void* host, int64_t ld, int64_t rows, int64_t cols, int es) {
+  // `inc` is the distance, in elements, between consecutive rows of a host column (1 for an
+  // ordinary column-major matrix); the device image is always dense along a column.
+  int upload(void* dev, int64_t dld, const void* host, int64_t ld, int64_t rows, int64_t cols, int es, int64_t inc = 1) {
     if (rows <= 0 || cols <= 0) return EIGAMD_OK;
     const size_t colbytes = (size_t)rows * es;
     if (colbytes > kChunk) {  // a single column does not fit a chunk: let the runtime stage it
+      if (inc != 1) return fail(EIGAMD_ERR_ARG, "a strided column above 64 MiB is not supported");
       HIP_TRY(hipMemcpy2DAsync(dev, dld * es, host, ld * es, colbytes, cols, hipMemcpyHostToDevice, h2d));
       return EIGAMD_OK;
     }
@@ -239,7 +242,8 @@ struct Staging {
       HIP_TRY(hipEventSynchronize(up_free[i]));
       char* pin = static_cast<char*>(up[i]);
       const char* src = static_cast<const char*>(host) + (size_t)c0 * ld * es;
-      copy_columns(pin, colbytes, src, (size_t)ld * es, colbytes, nc);
+      if (inc == 1) copy_columns(pin, colbytes, src, (size_t)ld * es, colbytes, nc);
+      else          copy_strided(pin, colbytes, 1, src, (size_t)ld * es, inc, rows, nc, es);
       HIP_TRY(hipMemcpy2DAsync(static_cast<char*>(dev) + (size_t)c0 * dld * es, dld * es, pin, colbytes, colbytes, nc,
                                hipMemcpyHostToDevice, h2d));
       HIP_TRY(hipEventRecord(up_free[i], h2d));
@@ -249,10 +253,11 @@ struct Staging {
 
   // The reverse, on the d2h stream; returns when the data is in the caller's memory.  The DMA
   // of chunk c+1 runs while the threads copy chunk c out of its pinned buffer.
-  int download(void* host, int64_t ld, const void* dev, int64_t dld, int64_t rows, int64_t cols, int es) {
+  int download(void* host, int64_t ld, const void* dev, int64_t dld, int64_t rows, int64_t cols, int es, int64_t inc = 1) {
     if (rows <= 0 || cols <= 0) return EIGAMD_OK;
     const size_t colbytes = (size_t)rows * es;
     if (colbytes > kChunk) {
+      if (inc != 1) return fail(EIGAMD_ERR_ARG, "a strided column above 64 MiB is not supported");
       HIP_TRY(hipMemcpy2DAsync(host, ld * es, dev, dld * es, colbytes, cols, hipMemcpyDeviceToHost, d2h));
       HIP_TRY(hipStreamSynchronize(d2h));
       return EIGAMD_OK;
@@ -272,8 +277,12 @@ struct Staging {
       const int64_t nc = std::min(per, cols - c0);
       if (c0 + per < cols && (rc = issue(c0 + per, cur ^ 1)) != EIGAMD_OK) return rc;
       HIP_TRY(hipEventSynchronize(down_ready[cur]));
-      copy_columns(static_cast<char*>(host) + (size_t)c0 * ld * es, (size_t)ld * es, static_cast<const char*>(down[cur]),
-                   colbytes, colbytes, nc);
+      if (inc == 1)
+        copy_columns(static_cast<char*>(host) + (size_t)c0 * ld * es, (size_t)ld * es, static_cast<const char*>(down[cur]),
+                     colbytes, colbytes, nc);
+      else
+        copy_strided(static_cast<char*>(host) + (size_t)c0 * ld * es, (size_t)ld * es, inc,
+                     static_cast<const char*>(down[cur]), colbytes, 1, rows, nc, es);
       cur ^= 1;
     }
     return EIGAMD_OK;
@@ -290,6 +299,28 @@ struct Staging {
       std::memcpy(dst + (size_t)c * dst_pitch + off, src + (size_t)c * src_pitch + off, len);
     });
   }
+  // The same for columns whose rows lie `dst_inc` / `src_inc` elements apart (a destination
+  // with a non-unit inner stride is gathered into, and scattered out of, the dense staging image).
+  template <typename E>
+  static void strided_piece(char* dst, int64_t dst_inc, const char* src, int64_t src_inc, int64_t count) {
+    E* d = reinterpret_cast<E*>(dst);
+    const E* s = reinterpret_cast<const E*>(src);
+    for (int64_t i = 0; i < count; ++i) d[i * dst_inc] = s[i * src_inc];
+  }
+  void copy_strided(char* dst, size_t dst_pitch, int64_t dst_inc, const char* src, size_t src_pitch, int64_t src_inc,
+                    int64_t rows, int64_t ncols, int es) {
+    const int64_t piece = 1 << 16;  // elements
+    const int64_t per_col = (rows + piece - 1) / piece;
+    struct E16 { uint64_t a, b; };
+    pool->parallel_for(ncols * per_col, [&](int64_t t) {
+      const int64_t c = t / per_col, r0 = (t % per_col) * piece, cnt = std::min(piece, rows - r0);
+      char* d = dst + (size_t)c * dst_pitch + (size_t)r0 * dst_inc * es;
+      const char* sp = src + (size_t)c * src_pitch + (size_t)r0 * src_inc * es;
+      if (es == 4) strided_piece<uint32_t>(d, dst_inc, sp, src_inc, cnt);
+      else if (es == 8) strided_piece<uint64_t>(d, dst_inc, sp, src_inc, cnt);
+      else strided_piece<E16>(d, dst_inc, sp, src_inc, cnt);
+    });
+  }
 };
 Staging& staging() {
   static Staging s;
@@ -300,7 +331,7 @@ int64_t round_up(int64_t v, int64_t q) { return (v + q - 1) / q * q; }
 
 int gemm_host_impl(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k,
                    const double alpha[2], const void* a, int64_t lda, const void* b, int64_t ldb,
-                   const double beta[2], void* c, int64_t ldc) {
+                   const double beta[2], void* c, int64_t ldc, int64_t c_inc = 1) {
   if (m == 0 || n == 0) return EIGAMD_OK;                          // level3_impl.h:59-60
   const bool beta_is_one = beta[0] == 1.0 && beta[1] == 0.0;
   if (k == 0 && beta_is_one) return EIGAMD_OK;                     // level3_impl.h:62-69
@@ -337,7 +368,7 @@ int gemm_host_impl(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k,
     const int64_t nb = std::min(panel, n - j0);
     HIP_TRY(hipStreamWaitEvent(st.d2h, computed[slot], 0));
     // Only the m x n window goes back: rows m..ldc-1 of C keep the caller's bytes.
-    return st.download(static_cast<char*>(c) + (size_t)j0 * ldc * es, ldc, cpanel(j0), dldc, m, nb, es);
+    return st.download(static_cast<char*>(c) + (size_t)j0 * ldc * es, ldc, cpanel(j0), dldc, m, nb, es, c_inc);
   };
   int slot = 0;
   int64_t prev = -1;
@@ -354,7 +385,7 @@ int gemm_host_impl(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k,
       if (rc != EIGAMD_OK) return rc;
     }
     if (!beta_is_zero &&
-        (rc = st.upload(cpanel(j0), dldc, static_cast<const char*>(c) + (size_t)j0 * ldc * es, ldc, m, nb, es)) != EIGAMD_OK)
+        (rc = st.upload(cpanel(j0), dldc, static_cast<const char*>(c) + (size_t)j0 * ldc * es, ldc, m, nb, es, c_inc)) != EIGAMD_OK)
       return rc;
     HIP_TRY(hipEventRecord(st.uploaded, st.h2d));
     HIP_TRY(hipStreamWaitEvent(st.stream, st.uploaded, 0));
@@ -453,6 +484,82 @@ int eigamd_gemm_host(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t 
   read_scalar(dtype, alpha, al);
   read_scalar(dtype, beta, be);
   return gemm_host_impl(dtype, opa, opb, m, n, k, al, a, lda, b, ldb, be, c, ldc);
+}
+
+// Staging for a product with one real operand: everything goes up, one device call, the
+// m x n window comes back (no column-panel pipeline: these forms are the rare ones).
+static int gemm_mixed_host_impl(int dtype, bool a_real, bool b_real, int opa, int opb, int64_t m, int64_t n, int64_t k,
+                                const double alpha[2], const void* a, int64_t lda, const void* b, int64_t ldb,
+                                const double beta[2], void* c, int64_t ldc, int64_t c_inc) {
+  if (m == 0 || n == 0) return EIGAMD_OK;
+  const bool beta_is_one = beta[0] == 1.0 && beta[1] == 0.0, beta_is_zero = beta[0] == 0.0 && beta[1] == 0.0;
+  if (k == 0 && beta_is_one) return EIGAMD_OK;
+  int rc = ensure_device();
+  if (rc != EIGAMD_OK) return rc;
+  const int es = kElemSize[dtype], esa = a_real ? es / 2 : es, esb = b_real ? es / 2 : es;
+  const int64_t a_rows = stored_rows_is_m(opa) ? m : k, a_cols = stored_rows_is_m(opa) ? k : m;
+  const int64_t b_rows = stored_rows_is_m(opb) ? k : n, b_cols = stored_rows_is_m(opb) ? n : k;
+  const int64_t dlda = round_up(std::max<int64_t>(a_rows, 1), 16), dldb = round_up(std::max<int64_t>(b_rows, 1), 16);
+  const int64_t dldc = round_up(m, 16);
+  Staging& st = staging();
+  std::lock_guard<std::mutex> lock(st.mu);
+  if ((rc = st.init()) != EIGAMD_OK) return rc;
+  if ((rc = st.reserve(0, (size_t)dlda * std::max<int64_t>(a_cols, 1) * esa)) != EIGAMD_OK) return rc;
+  if ((rc = st.reserve(1, (size_t)dldb * std::max<int64_t>(b_cols, 1) * esb)) != EIGAMD_OK) return rc;
+  if ((rc = st.reserve(2, (size_t)dldc * n * es)) != EIGAMD_OK) return rc;
+  if ((rc = st.upload(st.buf[0], dlda, a, lda, a_rows, a_cols, esa)) != EIGAMD_OK) return rc;
+  if ((rc = st.upload(st.buf[1], dldb, b, ldb, b_rows, b_cols, esb)) != EIGAMD_OK) return rc;
+  if (!beta_is_zero && (rc = st.upload(st.buf[2], dldc, c, ldc, m, n, es, c_inc)) != EIGAMD_OK) return rc;
+  HIP_TRY(hipEventRecord(st.uploaded, st.h2d));
+  HIP_TRY(hipStreamWaitEvent(st.stream, st.uploaded, 0));
+  HIP_TRY(gemm_mixed_device(dtype, a_real, b_real, opa, opb, m, n, k, alpha, st.buf[0], dlda, st.buf[1], dldb, beta,
+                            st.buf[2], dldc, st.stream));
+  HIP_TRY(hipEventRecord(st.computed, st.stream));
+  HIP_TRY(hipStreamWaitEvent(st.d2h, st.computed, 0));
+  return st.download(c, ldc, st.buf[2], dldc, m, n, es, c_inc);
+}
+
+static int check_ex(int dtype, int a_real, int b_real, int opa, int opb, int64_t m, int64_t n, int64_t k, int64_t lda,
+                    int64_t ldb, int64_t c_inc, int64_t ldc) {
+  if (dtype < 0 || dtype > 3) return fail(EIGAMD_ERR_ARG, "dtype out of range");
+  if ((a_real || b_real) && (dtype < C32 || (a_real && b_real)))
+    return fail(EIGAMD_ERR_ARG, "a real operand needs a complex result kind and a complex other operand");
+  if (c_inc < 1) return fail(EIGAMD_ERR_ARG, "inner stride of C must be positive");
+  int info = check_args(opa, opb, m, n, k, lda, ldb, std::max<int64_t>(ldc, std::max<int64_t>(1, m)));
+  // ldc >= max(1, m) for a dense C (blas/level3_impl.h:54); the columns of a strided C must not overlap
+  if (!info && ldc < (m > 0 ? (m - 1) * c_inc + 1 : 1)) info = 13;
+  if (info) return fail(EIGAMD_ERR_ARG, "invalid argument #" + std::to_string(info));
+  if (m > 0x7fffffff || n > 0x7fffffff || k > 0x7fffffff) return fail(EIGAMD_ERR_ARG, "extent exceeds 2^31-1");
+  return EIGAMD_OK;
+}
+
+int eigamd_gemm_ex_host(int dtype, int a_is_real, int b_is_real, int opa, int opb, int64_t m, int64_t n, int64_t k,
+                        const void* alpha, const void* a, int64_t lda, const void* b, int64_t ldb, const void* beta,
+                        void* c, int64_t c_inc, int64_t ldc) {
+  int rc = check_ex(dtype, a_is_real, b_is_real, opa, opb, m, n, k, lda, ldb, c_inc, ldc);
+  if (rc != EIGAMD_OK) return rc;
+  double al[2], be[2];
+  read_scalar(dtype, alpha, al);
+  read_scalar(dtype, beta, be);
+  if (!a_is_real && !b_is_real) return gemm_host_impl(dtype, opa, opb, m, n, k, al, a, lda, b, ldb, be, c, ldc, c_inc);
+  return gemm_mixed_host_impl(dtype, a_is_real != 0, b_is_real != 0, opa, opb, m, n, k, al, a, lda, b, ldb, be, c, ldc, c_inc);
+}
+
+int eigamd_gemm_mixed_dev(int dtype, int a_is_real, int b_is_real, int opa, int opb, int64_t m, int64_t n, int64_t k,
+                          const void* alpha, const void* d_a, int64_t lda, const void* d_b, int64_t ldb, const void* beta,
+                          void* d_c, int64_t ldc, void* stream) {
+  if (!a_is_real && !b_is_real) return fail(EIGAMD_ERR_ARG, "no real operand: use eigamd_gemm_dev");
+  int rc = check_ex(dtype, a_is_real, b_is_real, opa, opb, m, n, k, lda, ldb, 1, ldc);
+  if (rc != EIGAMD_OK) return rc;
+  if (m == 0 || n == 0) return EIGAMD_OK;
+  if ((rc = ensure_device()) != EIGAMD_OK) return rc;
+  double al[2], be[2];
+  read_scalar(dtype, alpha, al);
+  read_scalar(dtype, beta, be);
+  if (k == 0 && be[0] == 1.0 && be[1] == 0.0) return EIGAMD_OK;
+  HIP_TRY(gemm_mixed_device(dtype, a_is_real != 0, b_is_real != 0, opa, opb, m, n, k, al, d_a, lda, d_b, ldb, be, d_c, ldc,
+                            static_cast<hipStream_t>(stream)));
+  return EIGAMD_OK;
 }
 
 int eigamd_gemm_dev(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k,

@@ -63,6 +63,21 @@ template <typename T> __global__ void copy_matrix(const T* __restrict__ S, int64
   }
 }
 
+// Real matrix -> complex matrix with zero imaginary parts (the real operand of a mixed
+// real x complex product, gebp_traits<complex, real> / <real, complex>,
+// GeneralBlockPanelKernel.h:548-681, :925-1049).
+template <typename R, typename Z>
+__global__ void promote_real(const R* __restrict__ S, int64_t lds, int m, int n, Z* __restrict__ D, int64_t ldd) {
+  const int64_t total = (int64_t)m * n;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = idx / m, i = idx - j * m;
+    Z z;
+    z.x = S[i + j * lds];
+    z.y = 0;
+    D[i + j * ldd] = z;
+  }
+}
+
 struct Scratch {
   std::mutex mu;
   void* buf = nullptr;
@@ -178,6 +193,61 @@ hipError_t trmm_device(int kind, bool left, bool upper, int op, bool unit, int64
   if (left) { g.opa = op; g.A = X; g.lda = ldx; g.opb = OP_N; g.B = Y; g.ldb = ldy; g.ktri = eff_lower ? 1 : 2; }
   else      { g.opa = OP_N; g.A = Y; g.lda = ldy; g.opb = op; g.B = X; g.ldb = ldx; g.ktri = eff_lower ? 4 : 3; }
   g.C = B; g.ldc = ldb;
+  LX_TRY(launch_any(g, s));
+  return hipEventRecord(sc.done, s);
+}
+
+// C (complex) <- alpha op(A) op(B) + beta C where exactly one of A, B holds real scalars.
+//
+// Complex column-major A in plain form times a real B, with real alpha and beta, is a REAL
+// product on twice as many rows: the (re, im) pairs of a column of A and of C are consecutive
+// real numbers, and a real B acts on both parts alike.  That launch does half the arithmetic
+// of a complex product and needs no scratch.  Every other form promotes the real operand to
+// complex in scratch memory and runs the complex kernel.
+hipError_t gemm_mixed_device(int ckind, bool a_real, bool b_real, int opa, int opb, int64_t m, int64_t n, int64_t k,
+                             const double alpha[2], const void* A, int64_t lda, const void* B, int64_t ldb,
+                             const double beta[2], void* C, int64_t ldc, hipStream_t s) {
+  if (m <= 0 || n <= 0) return hipSuccess;
+  if (ckind < C32 || a_real == b_real) return hipErrorInvalidValue;
+  const int rkind = ckind - 2;
+  // conjugating a real operand does nothing
+  auto real_op = [](int op) { return (op == OP_T || op == OP_C) ? OP_T : OP_N; };
+  GemmCall g;
+  g.m = m; g.n = n; g.k = k;
+  g.alpha[0] = alpha[0]; g.alpha[1] = alpha[1];
+  g.beta[0] = beta[0]; g.beta[1] = beta[1];
+  g.C = C; g.ldc = ldc;
+  if (b_real && opa == OP_N && alpha[1] == 0.0 && beta[1] == 0.0 && m < (1 << 30)) {
+    g.kind = rkind;
+    g.m = 2 * m;
+    g.opa = OP_N; g.A = A; g.lda = 2 * lda;
+    g.opb = real_op(opb); g.B = B; g.ldb = ldb;
+    g.ldc = 2 * ldc;
+    return launch_any(g, s);
+  }
+  if (k <= 0) {  // nothing to promote: C <- beta C
+    g.kind = ckind; g.opa = OP_N; g.opb = OP_N; g.A = A; g.lda = std::max<int64_t>(lda, 1); g.B = B; g.ldb = std::max<int64_t>(ldb, 1);
+    return launch_any(g, s);
+  }
+  const int op_r = a_real ? opa : opb;
+  const bool plain = (op_r == OP_N || op_r == OP_CONJ);
+  const int64_t rr = a_real ? (plain ? m : k) : (plain ? k : n);   // stored rows / columns of the real operand
+  const int64_t rc = a_real ? (plain ? k : m) : (plain ? n : k);
+  const int64_t ldx = round16(rr);
+  Scratch& sc = scratch();
+  std::lock_guard<std::mutex> lock(sc.mu);
+  LX_TRY(acquire(sc, (size_t)ldx * rc * kElem[ckind], s));
+  const unsigned blocks = (unsigned)std::min<int64_t>(8192, (rr * rc + 255) / 256);
+  if (ckind == C32)
+    hipLaunchKernelGGL((promote_real<float, float2>), dim3(blocks), dim3(256), 0, s, (const float*)(a_real ? A : B),
+                       a_real ? lda : ldb, (int)rr, (int)rc, (float2*)sc.buf, ldx);
+  else
+    hipLaunchKernelGGL((promote_real<double, double2>), dim3(blocks), dim3(256), 0, s, (const double*)(a_real ? A : B),
+                       a_real ? lda : ldb, (int)rr, (int)rc, (double2*)sc.buf, ldx);
+  LX_TRY(hipGetLastError());
+  g.kind = ckind;
+  if (a_real) { g.opa = real_op(opa); g.A = sc.buf; g.lda = ldx; g.opb = opb; g.B = B; g.ldb = ldb; }
+  else        { g.opa = opa; g.A = A; g.lda = lda; g.opb = real_op(opb); g.B = sc.buf; g.ldb = ldx; }
   LX_TRY(launch_any(g, s));
   return hipEventRecord(sc.done, s);
 }

@@ -17,4 +17,10 @@ hipError_t symm_device(int kind, bool left, bool upper, bool herm, int64_t m, in
 hipError_t trmm_device(int kind, bool left, bool upper, int op, bool unit, int64_t m, int64_t n, const double alpha[2],
                        const void* A, int64_t lda, void* B, int64_t ldb, hipStream_t s);
 
+// C <- alpha * op(A) * op(B) + beta * C with C of the complex kind `ckind` and exactly one of
+// A, B holding real scalars of the matching precision (`a_real` / `b_real`).
+hipError_t gemm_mixed_device(int ckind, bool a_real, bool b_real, int opa, int opb, int64_t m, int64_t n, int64_t k,
+                             const double alpha[2], const void* A, int64_t lda, const void* B, int64_t ldb,
+                             const double beta[2], void* C, int64_t ldc, hipStream_t s);
+
 }  // namespace eigamd

@@ -88,6 +88,22 @@ def gemm_dev(opa, opb, alpha, a, b, beta, c, stream=None):
     return c
 
 
+def gemm_mixed_dev(opa, opb, alpha, a, b, beta, c, stream=None):
+    """c <- alpha * op(a) * op(b) + beta * c with c complex and exactly one of a, b holding real
+    scalars of the matching precision (``eigamd_gemm_mixed_dev``)."""
+    a_real, b_real = int(a.kind == c.kind - 2), int(b.kind == c.kind - 2)
+    oa, ob = _OPCODE[opa], _OPCODE[opb]
+    m, n = c.rows, c.cols
+    k = a.cols if oa in (_lib.OP_N, _lib.OP_CONJ) else a.rows
+    dt = _NP_OF_KIND[c.kind]
+    al, be = np.array([alpha], dtype=dt), np.array([beta], dtype=dt)
+    rc = lib.eigamd_gemm_mixed_dev(c.kind, a_real, b_real, oa, ob, m, n, k, ctypes.c_void_p(al.ctypes.data),
+                                   ctypes.c_void_p(a.ptr), a.ld, ctypes.c_void_p(b.ptr), b.ld,
+                                   ctypes.c_void_p(be.ctypes.data), ctypes.c_void_p(c.ptr), c.ld, _stream_ptr(stream))
+    _lib.check(rc, "eigamd_gemm_mixed_dev")
+    return c
+
+
 def trsm_dev(side, uplo, transa, diag, alpha, a, b, stream=None):
     """op(a) x = alpha b (side 'L') or x op(a) = alpha b (side 'R') on DeviceMatrix operands,
     x overwriting b; asynchronous on ``stream`` (``eigamd_trsm_dev``)."""

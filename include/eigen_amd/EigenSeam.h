@@ -11,7 +11,10 @@
 // (Eigen/src/Core/products/GeneralMatrixMatrix_BLAS.h:56-108) and
 // partial_lu_impl<T,StorageOrder,int> (Eigen/src/LU/PartialPivLU_LAPACKE.h:44-79) --
 // forwarding to the 64-bit C entry points.  Unlike the F77 route, a conjugated
-// column-major operand needs no temporary (EIGAMD_OP_CONJ).
+// column-major operand needs no temporary (EIGAMD_OP_CONJ), and the two forms of
+// general_matrix_matrix_product that Eigen's BLAS binding leaves on the built-in kernel
+// (doc/UsingBlasLapackBackends.dox:59-61) are bound as well: one real and one complex
+// operand, and a destination with a non-unit inner stride (ResInnerStride != 1).
 #ifndef EIGEN_AMD_EIGEN_SEAM_H
 #define EIGEN_AMD_EIGEN_SEAM_H
 
@@ -66,6 +69,63 @@ EIGAMD_PRODUCT_SEAM(double)
 EIGAMD_PRODUCT_SEAM(std::complex<float>)
 EIGAMD_PRODUCT_SEAM(std::complex<double>)
 #undef EIGAMD_PRODUCT_SEAM
+
+// ResInnerStride other than the constant 1 (a run-time stride, or a fixed stride > 1): rows of
+// the destination lie resIncr elements apart (blas_data_mapper with an inner stride,
+// GeneralMatrixMatrix.h:73-76).
+template <typename Index, typename T, int LhsOrder, bool ConjLhs, int RhsOrder, bool ConjRhs>
+struct eigamd_product_strided {
+  typedef gebp_traits<T, T> Traits;
+  static void run(Index rows, Index cols, Index depth, const T* lhs, Index lhsStride, const T* rhs, Index rhsStride,
+                  T* res, Index resIncr, Index resStride, T alpha, level3_blocking<T, T>&, GemmParallelInfo<Index>*) {
+    const int opa = LhsOrder == RowMajor ? (ConjLhs ? EIGAMD_OP_C : EIGAMD_OP_T) : (ConjLhs ? EIGAMD_OP_CONJ : EIGAMD_OP_N);
+    const int opb = RhsOrder == RowMajor ? (ConjRhs ? EIGAMD_OP_C : EIGAMD_OP_T) : (ConjRhs ? EIGAMD_OP_CONJ : EIGAMD_OP_N);
+    const T one(1);
+    eigamd_require(eigamd_gemm_ex_host(eigamd_kind<T>::value, 0, 0, opa, opb, rows, cols, depth, &alpha, lhs, lhsStride, rhs,
+                                       rhsStride, &one, res, resIncr, resStride),
+                   "eigamd_gemm_ex_host");
+  }
+};
+#define EIGAMD_PRODUCT_SEAM_STRIDED(T)                                                                          \
+  template <typename Index, int LhsOrder, bool ConjLhs, int RhsOrder, bool ConjRhs, int ResInnerStride>          \
+  struct general_matrix_matrix_product<Index, T, LhsOrder, ConjLhs, T, RhsOrder, ConjRhs, ColMajor, ResInnerStride> \
+      : eigamd_product_strided<Index, T, LhsOrder, ConjLhs, RhsOrder, ConjRhs> {};
+EIGAMD_PRODUCT_SEAM_STRIDED(float)
+EIGAMD_PRODUCT_SEAM_STRIDED(double)
+EIGAMD_PRODUCT_SEAM_STRIDED(std::complex<float>)
+EIGAMD_PRODUCT_SEAM_STRIDED(std::complex<double>)
+#undef EIGAMD_PRODUCT_SEAM_STRIDED
+
+// One real and one complex operand (gebp_traits<complex,real> / <real,complex>,
+// GeneralBlockPanelKernel.h:548-681, :925-1049); the result and alpha are complex.
+template <typename Index, typename L, int LhsOrder, bool ConjLhs, typename R, int RhsOrder, bool ConjRhs>
+struct eigamd_product_mixed {
+  typedef gebp_traits<L, R> Traits;
+  typedef typename ScalarBinaryOpTraits<L, R>::ReturnType ResScalar;
+  static void run(Index rows, Index cols, Index depth, const L* lhs, Index lhsStride, const R* rhs, Index rhsStride,
+                  ResScalar* res, Index resIncr, Index resStride, ResScalar alpha, level3_blocking<L, R>&,
+                  GemmParallelInfo<Index>*) {
+    const int opa = LhsOrder == RowMajor ? (ConjLhs ? EIGAMD_OP_C : EIGAMD_OP_T) : (ConjLhs ? EIGAMD_OP_CONJ : EIGAMD_OP_N);
+    const int opb = RhsOrder == RowMajor ? (ConjRhs ? EIGAMD_OP_C : EIGAMD_OP_T) : (ConjRhs ? EIGAMD_OP_CONJ : EIGAMD_OP_N);
+    const ResScalar one(1);
+    eigamd_require(eigamd_gemm_ex_host(eigamd_kind<ResScalar>::value, !NumTraits<L>::IsComplex, !NumTraits<R>::IsComplex, opa,
+                                       opb, rows, cols, depth, &alpha, lhs, lhsStride, rhs, rhsStride, &one, res, resIncr,
+                                       resStride),
+                   "eigamd_gemm_ex_host");
+  }
+};
+#define EIGAMD_PRODUCT_SEAM_MIXED(R)                                                                                   \
+  template <typename Index, int LhsOrder, bool ConjLhs, int RhsOrder, bool ConjRhs, int ResInnerStride>                 \
+  struct general_matrix_matrix_product<Index, std::complex<R>, LhsOrder, ConjLhs, R, RhsOrder, ConjRhs, ColMajor,        \
+                                       ResInnerStride>                                                                  \
+      : eigamd_product_mixed<Index, std::complex<R>, LhsOrder, ConjLhs, R, RhsOrder, ConjRhs> {};                        \
+  template <typename Index, int LhsOrder, bool ConjLhs, int RhsOrder, bool ConjRhs, int ResInnerStride>                 \
+  struct general_matrix_matrix_product<Index, R, LhsOrder, ConjLhs, std::complex<R>, RhsOrder, ConjRhs, ColMajor,        \
+                                       ResInnerStride>                                                                  \
+      : eigamd_product_mixed<Index, R, LhsOrder, ConjLhs, std::complex<R>, RhsOrder, ConjRhs> {};
+EIGAMD_PRODUCT_SEAM_MIXED(float)
+EIGAMD_PRODUCT_SEAM_MIXED(double)
+#undef EIGAMD_PRODUCT_SEAM_MIXED
 
 #ifdef EIGEN_PARTIALLU_H
 template <typename T> struct eigamd_lu {

@@ -67,6 +67,26 @@ int eigamd_gemm_dev(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k
                     const void* alpha, const void* d_a, int64_t lda, const void* d_b,
                     int64_t ldb, const void* beta, void* d_c, int64_t ldc, void* stream);
 
+/* ---- the forms Eigen keeps off the F77 route ------------------------------------
+ * general_matrix_matrix_product (Eigen/src/Core/products/GeneralMatrixMatrix.h:52-69) is
+ * also instantiated with one real and one complex operand (gebp_traits<complex,real> /
+ * <real,complex>, GeneralBlockPanelKernel.h:548-681, :925-1049) and with a destination
+ * whose rows lie resIncr elements apart (ResInnerStride; blas_data_mapper with an inner
+ * stride, util/BlasUtil.h).  No F77 routine expresses either, so Eigen's BLAS binding
+ * leaves them on the built-in kernel (doc/UsingBlasLapackBackends.dox:59-61); the
+ * header-level binding forwards them here.
+ *
+ * `dtype` is the kind of C, alpha and beta.  a_is_real / b_is_real: that operand holds
+ * real scalars of the matching precision (dtype must then be a complex kind, and at most
+ * one flag may be set).  C(i,j) is at c[i*c_inc + j*ldc] (c_inc >= 1, columns must not
+ * overlap).  eigamd_gemm_mixed_dev is the mixed product on matrices already in HBM. */
+int eigamd_gemm_ex_host(int dtype, int a_is_real, int b_is_real, int opa, int opb, int64_t m, int64_t n, int64_t k,
+                        const void* alpha, const void* a, int64_t lda, const void* b, int64_t ldb, const void* beta,
+                        void* c, int64_t c_inc, int64_t ldc);
+int eigamd_gemm_mixed_dev(int dtype, int a_is_real, int b_is_real, int opa, int opb, int64_t m, int64_t n, int64_t k,
+                          const void* alpha, const void* d_a, int64_t lda, const void* d_b, int64_t ldb, const void* beta,
+                          void* d_c, int64_t ldc, void* stream);
+
 /* ---- synthetic operands ------------------------------------------------------
  * U[-1,1) entries from a counter-based generator: element (i,j) depends only on
  * (seed, i, j), so host and device produce bit-identical matrices without a

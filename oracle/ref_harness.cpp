@@ -60,6 +60,47 @@ void opstar(int opa, int opb, int64_t m, int64_t n, int64_t k, const void* palph
 #undef OPSTAR_CASE
 }
 
+// The forms the F77 route cannot express: one real and one complex operand, and a
+// destination with an inner stride (test/mixingtypes.cpp, test/product.h:256-269).
+// L, R: scalar types of the operands; the result type follows from them.
+template <typename L, typename R>
+void opstar_ex(int opa, int opb, int64_t m, int64_t n, int64_t k, const void* palpha, const void* pa, int64_t lda,
+               const void* pb, int64_t ldb, const void* pbeta, void* pc, int64_t c_inc, int64_t ldc) {
+  typedef typename ScalarBinaryOpTraits<L, R>::ReturnType S;
+  typedef Map<const Matrix<L, Dynamic, Dynamic>, 0, OuterStride<> > AMap;
+  typedef Map<const Matrix<R, Dynamic, Dynamic>, 0, OuterStride<> > BMap;
+  typedef Map<Matrix<S, Dynamic, Dynamic>, 0, Stride<Dynamic, Dynamic> > CMapS;
+  const S alpha = *static_cast<const S*>(palpha), beta = *static_cast<const S*>(pbeta);
+  const bool an = (opa == 0 || opa == 3), bn = (opb == 0 || opb == 3);
+  AMap A(static_cast<const L*>(pa), an ? m : k, an ? k : m, OuterStride<>(lda));
+  BMap B(static_cast<const R*>(pb), bn ? k : n, bn ? n : k, OuterStride<>(ldb));
+  CMapS C(static_cast<S*>(pc), m, n, Stride<Dynamic, Dynamic>(ldc, c_inc));
+  if (beta == S(0)) C.setZero();
+  else if (beta != S(1)) C *= beta;
+  if (k == 0) return;
+#define OPSTAR_CASE(code, EA, EB) \
+  case code: C.noalias() += alpha * ((EA) * (EB)); break;
+  switch (opa * 4 + opb) {
+    OPSTAR_CASE(0, A, B)
+    OPSTAR_CASE(1, A, B.transpose())
+    OPSTAR_CASE(2, A, B.adjoint())
+    OPSTAR_CASE(3, A, B.conjugate())
+    OPSTAR_CASE(4, A.transpose(), B)
+    OPSTAR_CASE(5, A.transpose(), B.transpose())
+    OPSTAR_CASE(6, A.transpose(), B.adjoint())
+    OPSTAR_CASE(7, A.transpose(), B.conjugate())
+    OPSTAR_CASE(8, A.adjoint(), B)
+    OPSTAR_CASE(9, A.adjoint(), B.transpose())
+    OPSTAR_CASE(10, A.adjoint(), B.adjoint())
+    OPSTAR_CASE(11, A.adjoint(), B.conjugate())
+    OPSTAR_CASE(12, A.conjugate(), B)
+    OPSTAR_CASE(13, A.conjugate(), B.transpose())
+    OPSTAR_CASE(14, A.conjugate(), B.adjoint())
+    OPSTAR_CASE(15, A.conjugate(), B.conjugate())
+  }
+#undef OPSTAR_CASE
+}
+
 // The timed operation of bench/bench_gemm.cpp:161-165: c.noalias() += a * b in a
 // function the optimiser cannot fold into the caller.
 template <typename M> __attribute__((noinline)) void gemm_step(const M& a, const M& b, M& c) {
@@ -95,6 +136,24 @@ int ref_opstar(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k, con
     case 2: opstar<std::complex<float> >(opa, opb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc); return 0;
     case 3: opstar<std::complex<double> >(opa, opb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc); return 0;
   }
+  return -1;
+}
+
+// dtype: kind of C.  a_real / b_real: that operand holds real scalars of the same precision.
+int ref_opstar_ex(int dtype, int a_real, int b_real, int opa, int opb, int64_t m, int64_t n, int64_t k, const void* alpha,
+                  const void* a, int64_t lda, const void* b, int64_t ldb, const void* beta, void* c, int64_t c_inc,
+                  int64_t ldc) {
+  typedef std::complex<float> cf;
+  typedef std::complex<double> cd;
+#define EX(L, R) opstar_ex<L, R>(opa, opb, m, n, k, alpha, a, lda, b, ldb, beta, c, c_inc, ldc); return 0
+  if (a_real && b_real) return -1;
+  switch (dtype) {
+    case 0: if (a_real || b_real) return -1; EX(float, float);
+    case 1: if (a_real || b_real) return -1; EX(double, double);
+    case 2: if (a_real) { EX(float, cf); } else if (b_real) { EX(cf, float); } else { EX(cf, cf); }
+    case 3: if (a_real) { EX(double, cd); } else if (b_real) { EX(cd, double); } else { EX(cd, cd); }
+  }
+#undef EX
   return -1;
 }
 

@@ -131,6 +131,67 @@ template <typename S> static void structured_cases(const char* tag, double tol) 
 }
 #endif
 
+#ifdef USE_EIGAMD_SEAM
+// Forms that Eigen's own BLAS binding leaves on the built-in kernel and the header seam binds:
+// one real and one complex operand (test/mixingtypes.cpp) and a destination with an inner
+// stride (test/product.h:256-269).
+template <typename R> static void seam_only_cases(const char* tag, double tol) {
+  typedef std::complex<R> Z;
+  typedef Matrix<Z, Dynamic, Dynamic> MatZ;
+  typedef Matrix<R, Dynamic, Dynamic> MatR;
+  char name[96];
+  const int m = 157, n = 93, k = 201;
+  const MatZ az = MatZ::Random(m, k), bz = MatZ::Random(k, n), azt = MatZ::Random(k, m), c0 = MatZ::Random(m, n);
+  const MatR ar = MatR::Random(m, k), br = MatR::Random(k, n), brt = MatR::Random(n, k);
+  const MatZ arz = ar.template cast<Z>(), brz = br.template cast<Z>(), brtz = brt.template cast<Z>();
+  const Z s(2, -1);
+
+  MatZ c = az * br;
+  std::snprintf(name, sizeof name, "%s C = Az*Br (complex x real)", tag);
+  expect_close(name, c, az.lazyProduct(brz).eval(), tol);
+
+  c = c0; c.noalias() += ar * bz;
+  std::snprintf(name, sizeof name, "%s C += Ar*Bz (real x complex)", tag);
+  expect_close(name, c, (c0 + arz.lazyProduct(bz)).eval(), tol);
+
+  c = c0; c.noalias() -= s * (azt.adjoint() * brt.transpose());
+  std::snprintf(name, sizeof name, "%s C -= s*Az^H*Br^T", tag);
+  expect_close(name, c, (c0 - s * azt.adjoint().lazyProduct(brtz.transpose())).eval(), tol);
+
+  c = c0; c.noalias() += az.conjugate() * br;
+  std::snprintf(name, sizeof name, "%s C += conj(Az)*Br", tag);
+  expect_close(name, c, (c0 + az.conjugate().lazyProduct(brz)).eval(), tol);
+
+  Matrix<Z, Dynamic, Dynamic, RowMajor> cr(m, n);
+  cr.noalias() = ar * bz;
+  std::snprintf(name, sizeof name, "%s RowMajor C = Ar*Bz", tag);
+  expect_close(name, cr, arz.lazyProduct(bz).eval(), tol);
+
+  // destination with inner stride 2 and outer stride 2*m+3, real and complex
+  {
+    MatR buf = MatR::Random(2 * m + 3, n), keep = buf;
+    Map<MatR, 0, Stride<Dynamic, Dynamic> > cs(buf.data(), m, n, Stride<Dynamic, Dynamic>(2 * m + 3, 2));
+    const MatR before = cs;
+    cs.noalias() += ar * br;
+    std::snprintf(name, sizeof name, "%s strided C += Ar*Br", tag);
+    expect_close(name, MatR(cs), (before + ar.lazyProduct(br)).eval(), tol);
+    // the elements between the strided ones are untouched
+    Map<MatR, 0, Stride<Dynamic, Dynamic> > gaps(buf.data() + 1, m, n, Stride<Dynamic, Dynamic>(2 * m + 3, 2));
+    Map<MatR, 0, Stride<Dynamic, Dynamic> > gaps0(keep.data() + 1, m, n, Stride<Dynamic, Dynamic>(2 * m + 3, 2));
+    std::snprintf(name, sizeof name, "%s strided C: gaps untouched", tag);
+    expect_close(name, MatR(gaps), MatR(gaps0), 0.0);
+  }
+  {
+    MatZ buf = MatZ::Random(3 * m, n);
+    Map<MatZ, 0, Stride<Dynamic, Dynamic> > cs(buf.data(), m, n, Stride<Dynamic, Dynamic>(3 * m, 3));
+    const MatZ before = cs;
+    cs.noalias() -= az * br;
+    std::snprintf(name, sizeof name, "%s strided C -= Az*Br", tag);
+    expect_close(name, MatZ(cs), (before - az.lazyProduct(brz)).eval(), tol);
+  }
+}
+#endif
+
 static void lu_case(int n) {
   MatrixXd m1 = MatrixXd::Random(n, n);
   PartialPivLU<MatrixXd> plu(m1);
@@ -164,6 +225,10 @@ int main(int argc, char** argv) {
   structured_cases<double>("double", 1e-13);
   structured_cases<std::complex<float> >("cfloat", 2e-5);
   structured_cases<std::complex<double> >("cdouble", 1e-13);
+#endif
+#ifdef USE_EIGAMD_SEAM
+  seam_only_cases<float>("float", 2e-5);
+  seam_only_cases<double>("double", 1e-13);
 #endif
   lu_case(100);
   lu_case(1024);

@@ -60,6 +60,9 @@ def load_ref(variant=None):
     lib.ref_opstar.argtypes = [ctypes.c_int] * 3 + [ctypes.c_int64] * 3 + [ctypes.c_void_p, ctypes.c_void_p,
                                                                         ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+    lib.ref_opstar_ex.argtypes = [ctypes.c_int] * 5 + [ctypes.c_int64] * 3 + [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
     lib.ref_simd.restype = ctypes.c_char_p
     lib.ref_set_cache_sizes.argtypes = [ctypes.c_long] * 3
     for name in ("ref_blocked_lu_d", "ref_blocked_lu_s"):
@@ -99,6 +102,24 @@ def oracle_product64(kind, opa, opb, m, n, k, alpha, a, lda, b, ldb, beta, c, ld
                                                              ctypes.c_void_p, ctypes.c_long]
     f(int(opa in "TC"), int(opa in "CJ"), int(opb in "TC"), int(opb in "CJ"), m, n, k, _vp(al), _vp(a), lda, _vp(b),
       ldb, _vp(be), _vp(c), ldc)
+    return c
+
+
+def oracle_product_ex(opa, opb, m, n, k, alpha, a, lda, b, ldb, beta, c, c_inc, ldc):
+    """The forms no F77 routine expresses: one operand of real scalars beside a complex one
+    (read off the dtypes), and / or a destination whose rows lie c_inc elements apart."""
+    dt = c.dtype
+    kind = DTYPES.index(dt.type)
+    a_real = int(a.dtype.kind == "f" and dt.kind == "c")
+    b_real = int(b.dtype.kind == "f" and dt.kind == "c")
+    al, be = np.array([alpha], dtype=dt), np.array([beta], dtype=dt)
+    f = getattr(oracle, "oracle_product_ex_" + SUFFIX[kind])
+    f.restype = None
+    f.argtypes = [ctypes.c_int] * 6 + [ctypes.c_long] * 3 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long,
+                                                             ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p,
+                                                             ctypes.c_void_p, ctypes.c_long, ctypes.c_long]
+    f(a_real, b_real, int(opa in "TC"), int(opa in "CJ"), int(opb in "TC"), int(opb in "CJ"), m, n, k, _vp(al), _vp(a),
+      lda, _vp(b), ldb, _vp(be), _vp(c), c_inc, ldc)
     return c
 
 
