@@ -1052,6 +1052,7 @@ hipError_t make_streams(LuStreams& st, int base_workgroups, int per_cu, int* tot
     LU_TRY(hipExtStreamCreateWithCUMask(&st.update, (uint32_t)words, umask.data()));
   }
   st.panel_cus = want;
+  if (getenv("EIGAMD_LU_DEBUG")) fprintf(stderr, "eigen_amd LU: panel CUs %d of %d, base-case workgroups %d, %d per CU\n", want, total, base_workgroups, per_cu);
   return hipSuccess;
 }
 
