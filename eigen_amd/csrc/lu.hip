@@ -507,6 +507,7 @@ __global__ void __launch_bounds__(256) lu_rank_update(const T* __restrict__ A, c
 // lu_apply_plan then moves whole row segments with independent loads, instead of one
 // dependent load-store pair per transposition and column.
 constexpr int kPlanSpan = 256;
+constexpr int kMaxSub = 4;  // an outer step of the look-ahead spans at most kMaxSub * kPlanSpan columns
 struct SwapPlan {
   int count;
   int dst[2 * kPlanSpan];
@@ -743,9 +744,13 @@ template <typename T> struct Workspace {
   unsigned* generation; // host-side running count of pivot columns handed to lu_base_fused
   int* error;
   int fused_capacity;   // workgroups of lu_base_fused that are certainly resident together
-  SwapPlan* plan[2];    // scratch of lu_swap_plan / lu_apply_plan (alternating per look-ahead step)
-  T* linv[2];           // inverse of the current step's unit lower triangle, kPlanSpan^2 each
+  // Scratch of lu_swap_plan / lu_apply_plan and inverses of unit lower triangles (kPlanSpan^2
+  // each).  Sets [2 * kMaxSub): the look-ahead, alternating per outer step, one entry per
+  // kPlanSpan-wide piece of the step's block; the last set: blocked() itself (one stream).
+  SwapPlan* plan[2 * kMaxSub + 1];
+  T* linv[2 * kMaxSub + 1];
 };
+constexpr int kOwnScratch = 2 * kMaxSub;
 
 // unblocked_lu (PartialPivLU.h:357-412) on the rows x jbw sub-panel at P.
 template <typename T>
@@ -839,7 +844,7 @@ template <typename T> hipError_t apply_inverse(const T* X, int64_t bs, T* B, int
 // `base`, so the caller-level "+= k" of the reference (:481) is already applied.
 template <typename T>
 hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows, int64_t cols, int* transp,
-                   int64_t max_block, const Workspace<T>& w, hipStream_t s) {
+                   int64_t max_block, const Workspace<T>& w, hipStream_t s, int64_t force_block = 0) {
   T* A = base + row0 + col0 * ld;
   const int64_t size = std::min(rows, cols);
   if (size <= kMaxBase) {
@@ -849,13 +854,13 @@ hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows
     const int jbw = (int)std::min<int64_t>(cols, rows);
     LU_TRY(unblocked<T>(A, ld, rows, jbw, transp + row0, (int)row0, (int)col0, w, s));
     if (cols > jbw) {
-      LU_TRY(laswp<T>(base + (col0 + jbw) * ld, ld, cols - jbw, transp, (int)row0, (int)(row0 + jbw), w.plan[0], s));
+      LU_TRY(laswp<T>(base + (col0 + jbw) * ld, ld, cols - jbw, transp, (int)row0, (int)(row0 + jbw), w.plan[kOwnScratch], s));
       hipLaunchKernelGGL((lu_trsm_small<T, kMaxBase>), dim3((unsigned)((cols - jbw + 63) / 64)), dim3(64), 0, s, A, ld,
                          A + (int64_t)jbw * ld, ld, jbw, (int)(cols - jbw));
     }
     return hipGetLastError();
   }
-  const int64_t block = block_size_rule(size, max_block);
+  const int64_t block = force_block > 0 ? force_block : block_size_rule(size, max_block);
   for (int64_t k = 0; k < size; k += block) {
     const int64_t bs = std::min(size - k, block);
     const int64_t trows = rows - k - bs, tsize = size - k - bs;
@@ -880,17 +885,17 @@ hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows
       continue;
     }
     // transpositions of the panel on the columns to its left inside this level (A_0, :479-483)
-    LU_TRY(laswp<T>(base + col0 * ld, ld, k, transp, (int)(row0 + k), (int)(row0 + k + bs), w.plan[0], s));
+    LU_TRY(laswp<T>(base + col0 * ld, ld, k, transp, (int)(row0 + k), (int)(row0 + k + bs), w.plan[kOwnScratch], s));
     if (trows) {
       // ... and on the columns to its right (A_2, :488-489)
-      LU_TRY(laswp<T>(base + (col0 + k + bs) * ld, ld, tsize, transp, (int)(row0 + k), (int)(row0 + k + bs), w.plan[0], s));
+      LU_TRY(laswp<T>(base + (col0 + k + bs) * ld, ld, tsize, transp, (int)(row0 + k), (int)(row0 + k + bs), w.plan[kOwnScratch], s));
       T* A11 = A + k + k * ld;
       T* A12 = A + k + (k + bs) * ld;
       T* A21 = A + (k + bs) + k * ld;
       T* A22 = A + (k + bs) + (k + bs) * ld;
       if (inverse_applies<T>(bs)) {                                    // (:492)
-        LU_TRY(make_inverse<T>(A11, ld, bs, w.linv[0], s));
-        LU_TRY(apply_inverse<T>(w.linv[0], bs, A12, ld, tsize, s));
+        LU_TRY(make_inverse<T>(A11, ld, bs, w.linv[kOwnScratch], s));
+        LU_TRY(apply_inverse<T>(w.linv[kOwnScratch], bs, A12, ld, tsize, s));
       } else {
         LU_TRY(trsm_unit_lower<T>(A11, A12, ld, bs, tsize, s));
       }
@@ -923,12 +928,46 @@ struct LuStreams {
   int panel_cus = 0;               // CUs set aside for the panel stream (0: none, streams share the chip)
 };
 
+// Width of an outer step of the look-ahead.  The block-size rule of the reference (at most
+// 256) fixes how a panel is factorised; the TRAILING update may take several such panels at
+// once: a step of width W factorises its W columns with blocks of 256 (blocked(), on the panel
+// stream: the 256-wide panels, their transpositions, solves and products inside the W columns)
+// and then updates the columns to the right with ONE product of reduction length W.  The
+// arithmetic per element is the same sum of products, accumulated in one launch instead of
+// W / 256; the trailing matrix is read and written W / 256 times less often, which is what
+// bounds a k = 256 product (55 TFLOP/s at 32768^2 against 67 at k = 1024).
+// While the trailing matrix is large the step is bounded by the trailing product and wide steps
+// pay; once the panel (a chain of latency-bound kernels on its own few compute units) is what
+// the update stream waits for, wide steps only lengthen that chain, so the width falls back to
+// one panel per step.  `remaining` = columns from the step's first column to the end.
+// EIGAMD_LU_WIDE fixes the width (a multiple of 256 up to kMaxSub * 256; 256 = one panel per
+// step); EIGAMD_LU_WIDE_T4 / _T2 move the thresholds.
+struct WidthRule {
+  int64_t fixed = 0, t4 = 26624, t2 = 18432;
+};
+const WidthRule& width_rule() {
+  static const WidthRule r = [] {
+    WidthRule v;
+    if (const char* e = getenv("EIGAMD_LU_WIDE")) v.fixed = atoll(e);
+    if (const char* e = getenv("EIGAMD_LU_WIDE_T4")) v.t4 = atoll(e);
+    if (const char* e = getenv("EIGAMD_LU_WIDE_T2")) v.t2 = atoll(e);
+    return v;
+  }();
+  return r;
+}
+int64_t outer_block(int64_t remaining, int64_t rule_block) {
+  if (rule_block < kPlanSpan) return rule_block;  // small matrices: the reference's own block
+  const WidthRule& r = width_rule();
+  int64_t w = r.fixed > 0 ? r.fixed : (remaining >= r.t4 ? 4 * kPlanSpan : (remaining >= r.t2 ? 2 * kPlanSpan : kPlanSpan));
+  return std::max<int64_t>(kPlanSpan, std::min<int64_t>(w / kPlanSpan * kPlanSpan, (int64_t)kMaxSub * kPlanSpan));
+}
+
 template <typename T>
 hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* transp, int64_t max_block,
                              const Workspace<T>& w, const LuStreams& st, hipStream_t upd) {
   const int64_t size = std::min(rows, cols);
   if (size <= kMaxBase) return blocked<T>(A, ld, 0, 0, rows, cols, transp, max_block, w, upd);
-  const int64_t block = block_size_rule(size, max_block);
+  const int64_t rule_block = block_size_rule(size, max_block);
   hipStream_t pan = st.panel;
   hipStream_t caller = upd;
   if (st.update) {  // the updates run on the stream that leaves the panel's CUs alone
@@ -938,32 +977,50 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
   }
   LU_TRY(hipEventRecord(st.ready, upd));  // everything queued before the call
   int step = 0;
-  for (int64_t k = 0; k < size; k += block, ++step) {
-    const int64_t bs = std::min(size - k, block);
+  for (int64_t k = 0, bs = 0; k < size; k += bs, ++step) {
+    bs = std::min(size - k, outer_block(size - k, rule_block));
     const int64_t trows = rows - k - bs, tsize = size - k - bs;
-    const int k0 = (int)k, k1 = (int)(k + bs);
-    T* A11 = A + k + k * ld;
-    T* A21 = A + (k + bs) + k * ld;
-    // Per-step scratch alternates: the panel stream prepares step k+1 while the update stream
-    // still uses what belongs to step k.
-    SwapPlan* plan = w.plan[step & 1];
-    T* linv = w.linv[step & 1];
-    const bool planned = bs > 32 && bs <= kPlanSpan;  // one plan serves the three column ranges of this step
-    const bool inverted = inverse_applies<T>(bs) && trows > 0;
+    // The step's block in pieces of at most kPlanSpan rows: one swap plan and one inverted
+    // triangle per piece.  Per-step scratch alternates: the panel stream prepares step k+1
+    // while the update stream still uses what belongs to step k.
+    const int nsub = (int)((bs + kPlanSpan - 1) / kPlanSpan);
+    SwapPlan* const* plan = &w.plan[(step & 1) * kMaxSub];
+    T* const* linv = &w.linv[(step & 1) * kMaxSub];
+    auto sub_begin = [&](int i) { return (int64_t)i * kPlanSpan; };
+    auto sub_size = [&](int i) { return std::min<int64_t>(kPlanSpan, bs - sub_begin(i)); };
+    const bool planned = bs > 32;
     LU_TRY(hipStreamWaitEvent(pan, st.ready, 0));
-    LU_TRY(blocked<T>(A, ld, k, k, trows + bs, bs, transp, 16, w, pan));
-    if (planned) LU_TRY(make_plan(transp, k0, k1, plan, pan));
-    if (inverted) LU_TRY(make_inverse<T>(A11, ld, bs, linv, pan));
+    LU_TRY(blocked<T>(A, ld, k, k, trows + bs, bs, transp, 16, w, pan, bs > rule_block ? rule_block : 0));
+    if (planned)
+      for (int i = 0; i < nsub; ++i)
+        LU_TRY(make_plan(transp, (int)(k + sub_begin(i)), (int)(k + sub_begin(i) + sub_size(i)), plan[i], pan));
+    if (trows > 0)
+      for (int i = 0; i < nsub; ++i)
+        if (inverse_applies<T>(sub_size(i)))
+          LU_TRY(make_inverse<T>(A + (k + sub_begin(i)) * (ld + 1), ld, sub_size(i), linv[i], pan));
     LU_TRY(hipEventRecord(st.factored, pan));
     LU_TRY(hipStreamWaitEvent(upd, st.factored, 0));
-    auto swap_rows = [&](T* cols, int64_t ncols) {
-      return planned ? apply_plan<T>(cols, ld, ncols, plan, upd) : laswp<T>(cols, ld, ncols, transp, k0, k1, plan, upd);
+    // the step's transpositions, in order, on `ncols` columns
+    auto swap_rows = [&](T* cols, int64_t ncols) -> hipError_t {
+      if (!planned) return laswp<T>(cols, ld, ncols, transp, (int)k, (int)(k + bs), nullptr, upd);
+      for (int i = 0; i < nsub; ++i) LU_TRY(apply_plan<T>(cols, ld, ncols, plan[i], upd));
+      return hipSuccess;
     };
-    auto solve = [&](T* A12, int64_t ncols) {
-      return inverted ? apply_inverse<T>(linv, bs, A12, ld, ncols, upd) : trsm_unit_lower<T>(A11, A12, ld, bs, ncols, upd);
+    // A12 <- L^-1 A12 with L the unit lower triangle of the step's bs x bs block, piece by piece:
+    // the piece's own triangle (inverted where that applies), then the rows of the later pieces.
+    auto solve = [&](T* A12, int64_t ncols) -> hipError_t {
+      for (int i = 0; i < nsub; ++i) {
+        const int64_t o = sub_begin(i), sb = sub_size(i);
+        const T* L = A + (k + o) * (ld + 1);
+        if (inverse_applies<T>(sb)) LU_TRY(apply_inverse<T>(linv[i], sb, A12 + o, ld, ncols, upd));
+        else LU_TRY(trsm_unit_lower<T>(L, A12 + o, ld, sb, ncols, upd));
+        if (o + sb < bs) LU_TRY(gemm_minus3<T>(bs - o - sb, ncols, sb, L + sb, ld, A12 + o, ld, A12 + o + sb, ld, upd));
+      }
+      return hipSuccess;
     };
-    // columns of the next panel first
-    const int64_t nb = trows ? std::min<int64_t>(tsize, block) : 0;
+    T* A21 = A + (k + bs) + k * ld;
+    // columns of the next step's block first
+    const int64_t nb = trows ? std::min<int64_t>(tsize, outer_block(tsize, rule_block)) : 0;
     if (nb > 0) {
       T* A12 = A + k + (k + bs) * ld;
       LU_TRY(swap_rows(A + (k + bs) * ld, nb));
@@ -1066,8 +1123,9 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   const size_t off_side = 64;  // first_zero, nswaps, arrived, exited, error live in the first 64 bytes
   const size_t off_tops = off_side + round64(sizeof(Side<T>));
   const size_t off_plan = off_tops + round64(2 * sizeof(BaseTop<T>));
-  const size_t off_linv = off_plan + 2 * round64(sizeof(SwapPlan));
-  const size_t off_partials = off_linv + 2 * round64((size_t)kPlanSpan * kPlanSpan * sizeof(T));
+  constexpr int kSets = 2 * kMaxSub + 1;
+  const size_t off_linv = off_plan + kSets * round64(sizeof(SwapPlan));
+  const size_t off_partials = off_linv + kSets * round64((size_t)kPlanSpan * kPlanSpan * sizeof(T));
   const size_t off_slots = off_partials + round64(nparts * sizeof(Candidate<T>));
   const size_t nslots = 2 * std::min<size_t>(nparts, kMaxFusedParts);
   const size_t need = off_slots + round64(nslots * sizeof(BaseSlot<T>));
@@ -1095,7 +1153,7 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   w.generation = &sc.generation;
   w.side = reinterpret_cast<Side<T>*>(p + off_side);
   w.tops = reinterpret_cast<BaseTop<T>*>(p + off_tops);
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < kSets; ++i) {
     w.plan[i] = reinterpret_cast<SwapPlan*>(p + off_plan + i * round64(sizeof(SwapPlan)));
     w.linv[i] = reinterpret_cast<T*>(p + off_linv + i * round64((size_t)kPlanSpan * kPlanSpan * sizeof(T)));
   }
