@@ -29,7 +29,10 @@ namespace eigamd {
 
 namespace {
 
-constexpr int kRowsPerBlock = 256;  // rows of the panel one workgroup owns
+#ifndef EIGAMD_LU_ROWS_PER_BLOCK
+#define EIGAMD_LU_ROWS_PER_BLOCK 256
+#endif
+constexpr int kRowsPerBlock = EIGAMD_LU_ROWS_PER_BLOCK;  // rows of the panel one workgroup owns
 constexpr int kMaxBase = 16;        // widest unblocked panel (UnBlockedBound, PartialPivLU.h:336)
 
 template <typename T> struct Candidate {
