@@ -83,7 +83,8 @@ int check_args(int opa, int opb, int64_t m, int64_t n, int64_t k, int64_t lda, i
 }
 
 int ensure_device() {
-  static int state = 0;  // 0 unknown, 1 ok, -1 none
+  static std::atomic<int> state_cache{0};  // 0 unknown, 1 ok, -1 none
+  int state = state_cache.load();
   if (state == 0) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -98,6 +99,7 @@ int ensure_device() {
       else
         state = -1;
     }
+    state_cache.store(state);
   }
   if (state < 0) return fail(EIGAMD_ERR_NO_GPU, "no gfx950 (MI355X) device is visible; this library has no CPU path");
   return EIGAMD_OK;
@@ -323,8 +325,8 @@ struct Staging {
   }
 };
 Staging& staging() {
-  static Staging s;
-  return s;
+  static Staging s[kMaxDevices];
+  return s[current_device_slot()];
 }
 
 int64_t round_up(int64_t v, int64_t q) { return (v + q - 1) / q * q; }

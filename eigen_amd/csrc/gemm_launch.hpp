@@ -43,6 +43,15 @@ inline const Tuning& tuning() {
   return t;
 }
 
+// One instance per device: scratch memory, streams and events belong to the device that was
+// current when they were created.
+constexpr int kMaxDevices = 16;
+inline int current_device_slot() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
+  return d;
+}
+
 hipError_t launch_gemm_f32(const GemmCall&, hipStream_t);
 hipError_t launch_gemm_f64(const GemmCall&, hipStream_t);
 hipError_t launch_gemm_c32(const GemmCall&, hipStream_t);

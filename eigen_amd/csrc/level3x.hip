@@ -85,8 +85,8 @@ struct Scratch {
   hipEvent_t done = nullptr;
 };
 Scratch& scratch() {
-  static Scratch s;
-  return s;
+  static Scratch s[kMaxDevices];
+  return s[current_device_slot()];
 }
 
 #define LX_TRY(expr)                 \

@@ -1059,8 +1059,8 @@ struct LuScratch {
   LuStreams streams;
 };
 LuScratch& scratch() {
-  static LuScratch s;
-  return s;
+  static LuScratch s[kMaxDevices];
+  return s[current_device_slot()];
 }
 
 // Streams of the look-ahead.  When the chip has CUs to spare (EIGAMD_LU_PANEL_CUS, default

@@ -164,8 +164,8 @@ struct InvScratch {
   hipEvent_t done = nullptr;  // last use of buf
 };
 InvScratch& inv_scratch() {
-  static InvScratch s;
-  return s;
+  static InvScratch s[kMaxDevices];
+  return s[current_device_slot()];
 }
 
 #define TR_TRY(expr)                 \
