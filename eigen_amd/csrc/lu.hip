@@ -222,8 +222,8 @@ __device__ __forceinline__ bool get_value(const unsigned long long* p, float& v,
   return (unsigned)(w >> 32) == G;
 }
 
-// Largest |a| / smallest row over the workgroup, result in every thread; safe to call
-// repeatedly.
+// Largest |a| / smallest row over the workgroup, result in every thread.  One barrier; the
+// caller must separate two calls by a barrier of its own (lu_base_fused has one per column).
 template <typename T> __device__ Candidate<T> block_best_all(T val, int row) {
   __shared__ T s_val[kRowsPerBlock / 64];
   __shared__ int s_row[kRowsPerBlock / 64];
@@ -240,7 +240,6 @@ template <typename T> __device__ Candidate<T> block_best_all(T val, int row) {
 #pragma unroll
   for (int w = 1; w < kRowsPerBlock / 64; ++w)
     if (better(s_val[w], s_row[w], c.val, c.row)) { c.val = s_val[w]; c.row = s_row[w]; }
-  __syncthreads();
   return c;
 }
 
@@ -258,6 +257,7 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
                   unsigned gen0, int* __restrict__ error, int* __restrict__ first_zero, int* __restrict__ nswaps) {
   __shared__ T s_u[kMaxBase];
   __shared__ T s_top[kMaxBase];
+  __shared__ int s_win_row, s_flags;   // the winner's row; 1: the pivot is exactly zero, 2: gave up waiting
   const int nparts = gridDim.x;
   const int r = blockIdx.x * kRowsPerBlock + threadIdx.x;
   const bool valid = r < rows;
@@ -289,70 +289,87 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
 #pragma unroll
       for (int c = 0; c < kMaxBase; ++c) put_value(&top->data[c * Words<T>::N], row[c], G);
     }
-    // every workgroup's candidate of generation G
-    T val = (T)-1;
-    int prow = kNoRow;
-    unsigned spins = 0;
-    bool failed = false;
-    for (;;) {
-      bool ready = true;
-      val = (T)-1;
-      prow = kNoRow;
-      for (int i = threadIdx.x; i < nparts; i += kRowsPerBlock) {
-        T v;
-        const bool okv = get_value(buf[i].val, v, G);
-        const unsigned long long w = coherent_load(&buf[i].row);
-        if (!okv || (unsigned)(w >> 32) != G) {
-          ready = false;
-        } else {
-          const int rr = (int)(unsigned)w;
-          if (better(v, rr, val, prow)) { val = v; prow = rr; }
+    // Wavefront 0 alone talks to the exchange area: it polls every workgroup's candidate of
+    // generation G (lane = slot), picks the winner with shuffles, then fetches the two rows that
+    // matter -- panel row jj and, when they are exchanged, the winner's row -- and leaves them in
+    // LDS.  No workgroup barrier sits inside a polling loop; the other wavefronts wait at one.
+    if (threadIdx.x < 64) {
+      const int lane = threadIdx.x;
+      T val = (T)-1;
+      int prow = kNoRow;
+      unsigned spins = 0;
+      bool failed = false;
+      for (;;) {
+        bool ready = true;
+        val = (T)-1;
+        prow = kNoRow;
+        for (int i = lane; i < nparts; i += 64) {
+          T v;
+          const bool okv = get_value(buf[i].val, v, G);
+          const unsigned long long w = coherent_load(&buf[i].row);
+          if (!okv || (unsigned)(w >> 32) != G) {
+            ready = false;
+          } else {
+            const int rr = (int)(unsigned)w;
+            if (better(v, rr, val, prow)) { val = v; prow = rr; }
+          }
+        }
+        if (__all(ready ? 1 : 0)) break;
+        ++spins;
+        const bool give_up = spins > kSpinLimit || ((spins & 255u) == 0 && coherent_load(error) != 0);
+        if (__any(give_up ? 1 : 0)) { failed = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      // the same winner in every lane, hence in every workgroup
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const T ov = __shfl_xor(val, off, 64);
+        const int orow = __shfl_xor(prow, off, 64);
+        if (better(ov, orow, val, prow)) { val = ov; prow = orow; }
+      }
+      if (prow == kNoRow) {  // nothing comparable in the column (NaNs): no exchange, pivot = the diagonal entry
+        prow = jj;
+        val = (T)1;
+      }
+      const bool zero_w = !(val != (T)0);  // exactly zero
+      const bool swap_w = !zero_w && prow != jj;
+      if (!failed) {
+        const unsigned long long* src_top = top->data;
+        const unsigned long long* src_win = buf[swap_w ? prow / kRowsPerBlock : 0].data;
+        for (;;) {
+          bool ready = true;
+          T v = (T)0;
+          if (lane < kMaxBase) ready = get_value(&src_top[lane * Words<T>::N], v, G);
+          else if (lane < 2 * kMaxBase && swap_w) ready = get_value(&src_win[(lane - kMaxBase) * Words<T>::N], v, G);
+          if (__all(ready ? 1 : 0)) {
+            if (lane < kMaxBase) {
+              s_top[lane] = v;
+              if (!swap_w) s_u[lane] = v;
+            } else if (lane < 2 * kMaxBase && swap_w) {
+              s_u[lane - kMaxBase] = v;
+            }
+            break;
+          }
+          ++spins;
+          const bool give_up = spins > kSpinLimit || ((spins & 255u) == 0 && coherent_load(error) != 0);
+          if (__any(give_up ? 1 : 0)) { failed = true; break; }
+          __builtin_amdgcn_s_sleep(1);
         }
       }
-      if (__syncthreads_and(ready ? 1 : 0)) break;
-      ++spins;
-      const bool give_up = spins > kSpinLimit || ((spins & 255u) == 0 && coherent_load(error) != 0);
-      if (__syncthreads_or(give_up ? 1 : 0)) { failed = true; break; }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    if (failed) {
-      if (threadIdx.x == 0) coherent_store(error, 1);
-      break;
-    }
-    // the same winner in every workgroup
-    Candidate<T> win = block_best_all<T>(val, prow);
-    if (win.row == kNoRow) {  // nothing comparable in the column (NaNs): no exchange, pivot = the diagonal entry
-      win.row = jj;
-      win.val = (T)1;
-    }
-    const bool zero = !(win.val != (T)0);  // exactly zero
-    const bool swap = !zero && win.row != jj;
-    // the two rows: panel row jj, and the winner's row when they are exchanged
-    const unsigned long long* src_top = top->data;
-    const unsigned long long* src_win = buf[swap ? win.row / kRowsPerBlock : 0].data;
-    for (;;) {
-      bool ready = true;
-      if (threadIdx.x < kMaxBase) {
-        T v;
-        ready = get_value(&src_top[threadIdx.x * Words<T>::N], v, G);
-        s_top[threadIdx.x] = v;
-      } else if (threadIdx.x < 2 * kMaxBase && swap) {
-        T v;
-        ready = get_value(&src_win[(threadIdx.x - kMaxBase) * Words<T>::N], v, G);
-        s_u[threadIdx.x - kMaxBase] = v;
+      if (lane == 0) {
+        s_win_row = prow;
+        s_flags = (zero_w ? 1 : 0) | (failed ? 2 : 0);
       }
-      if (__syncthreads_and(ready ? 1 : 0)) break;
-      ++spins;
-      const bool give_up = spins > kSpinLimit || ((spins & 255u) == 0 && coherent_load(error) != 0);
-      if (__syncthreads_or(give_up ? 1 : 0)) { failed = true; break; }
-      __builtin_amdgcn_s_sleep(1);
     }
-    if (failed) {
+    __syncthreads();
+    if (s_flags & 2) {
       if (threadIdx.x == 0) coherent_store(error, 1);
       break;
     }
-    if (!swap && threadIdx.x < kMaxBase) s_u[threadIdx.x] = s_top[threadIdx.x];
-    __syncthreads();
+    Candidate<T> win;
+    win.row = s_win_row;
+    const bool zero = (s_flags & 1) != 0;
+    const bool swap = !zero && win.row != jj;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       transp[jj] = row_offset + win.row;
       if (zero) atomicCAS(first_zero, -1, col_global + jj);  // keep the FIRST zero pivot (PartialPivLU.h:391-396)
@@ -381,7 +398,10 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
         else if (c > jj) row[c] = row[c] - l * s_u[c];
       }
     }
-    __syncthreads();  // s_u / s_top are rewritten in the next column
+    // No barrier here: wavefront 0 rewrites s_u / s_top / s_win_row only after the barrier inside
+    // the next column's block_best_all, which every wavefront reaches after this update; and the
+    // wavefronts rewrite their block_best_all slots only after the barrier above, behind which
+    // nobody reads them any more.
   }
 
   if (valid) {
