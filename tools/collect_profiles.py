@@ -17,10 +17,15 @@ with open(os.path.join(R, "profiles", f"{tag}_kernel_trace_stats_bench.txt"), "w
     f.write(" workgroups  calls     avg_ms     min_ms     max_ms  kernel\n")
     for n, g, c, a, mn, mx in rows:
         f.write(f" {g:10d} {c:6d} {a:10.3f} {mn:10.3f} {mx:10.3f}  {n}\n")
-    head = [r for r in rows if "gemm_kernel<1" in r[0] and r[2] >= 10]
+    # the timed launches: f64 kernel, one workgroup per 256 x 128 tile of a 16384^2 C, full reduction length (the SYRK leg
+    # and TRMM legs launch the same grid, but skip tiles or k-tiles: they are told apart by their duration)
+    wg = (16384 // 256) * (16384 // 128)
+    durs = [d for (d,) in cur.execute("select (end-start)/1e6 from kernels where name like '%gemm_kernel<1%' and grid_x/workgroup_x = ?", (wg,))]
+    head = [d for d in durs if d > 0.9 * max(durs)] if durs else []
     if head:
         f.write(f"\nbench.py's own HIP-event average of the timed dgemm 16384^3 launches in the same run: {b['roofline']['avg_launch_ms']} ms "
-                f"(trace: {head[0][3]:.3f} ms over {head[0][2]} launches, warm-up included); value {b['value']} TFLOP/s\n")
+                f"(trace: {sum(head) / len(head):.3f} ms over the {len(head)} launches of that product, warm-up included; the other "
+                f"{len(durs) - len(head)} launches of the same grid are the SYRK and TRMM legs); value {b['value']} TFLOP/s\n")
 json.dump(b, open(os.path.join(R, "profiles", f"{tag}_bench_n1.json"), "w"), indent=1)
 pmc = open(os.path.join(src, "pmc_gemm16384.txt")).read()
 open(os.path.join(R, "profiles", f"{tag}_pmc_gemm16384.txt"), "w").write(pmc)
