@@ -28,14 +28,20 @@ struct GemmCall {
 // Block-to-tile mapping knobs; the defaults are what the shipped library uses, the
 // environment overrides exist for profiling experiments only.
 struct Tuning {
-  int group_m = 8;
+  int group_m = 0;  // 0: the kind's default (default_group_m)
   int xcd_remap = 1;
   int extra_lds = 0;  // bytes of unused dynamic LDS per block (lowers blocks per CU)
 };
+// Tile rows walked together by consecutive workgroups.  The 32 workgroups an XCD runs at a time
+// should cover a square patch of C, which needs the fewest distinct rows of A and columns of B
+// per k-step in that XCD's L2: 4 x 8 tiles of 256 x 128 for f64 (L2 hit 80 % against 65 % with
+// groups of 8, L2 <-> fabric reads per 16384^3 product 80 GB against 148 GB), 8 x 4 for the others.
+template <int KIND> constexpr int default_group_m() { return KIND == F64 ? 4 : 8; }
+
 inline const Tuning& tuning() {
   static const Tuning t = [] {
     Tuning v;
-    if (const char* e = std::getenv("EIGAMD_GROUP_M")) v.group_m = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("EIGAMD_GROUP_M")) v.group_m = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("EIGAMD_XCD_REMAP")) v.xcd_remap = std::atoi(e) != 0;
     if (const char* e = std::getenv("EIGAMD_EXTRA_LDS")) v.extra_lds = std::max(0, std::atoi(e));
     return v;
@@ -78,7 +84,7 @@ static hipError_t launch_region(const GemmCall& c, int64_t r0, int64_t c0, int64
   p.beta[0] = c.beta[0]; p.beta[1] = c.beta[1];
   p.conj_a = (c.opa == OP_C || c.opa == OP_CONJ);
   p.conj_b = (c.opb == OP_C || c.opb == OP_CONJ);
-  p.group_m = tuning().group_m;
+  p.group_m = tuning().group_m > 0 ? tuning().group_m : default_group_m<KIND>();
   // A triangular destination leaves about half of the tiles empty, a triangular operand gives
   // the tiles very different reduction lengths: contiguous runs of the tile sequence per XCD
   // would give the XCDs very different amounts of work, round-robin does not.
