@@ -76,6 +76,12 @@ for _name in ("ssyrk_", "dsyrk_", "csyrk_", "zsyrk_"):
     _f = getattr(lib, _name)
     _f.restype = ctypes.c_int
     _f.argtypes = [ctypes.c_char_p] * 2 + [_i32p, _i32p, _vp, _vp, _i32p, _vp, _vp, _i32p]
+for _name in ("cherk_", "zherk_"):
+    _f = getattr(lib, _name)
+    _f.restype = ctypes.c_int
+    _f.argtypes = [ctypes.c_char_p] * 2 + [_i32p, _i32p, _vp, _vp, _i32p, _vp, _vp, _i32p]
+lib.eigamd_herk_dev.restype = ctypes.c_int
+lib.eigamd_herk_dev.argtypes = [ctypes.c_int] * 3 + [_i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp]
 lib.eigamd_syrk_dev.restype = ctypes.c_int
 lib.eigamd_syrk_dev.argtypes = [ctypes.c_int] * 3 + [_i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp]
 for _name in ("ssymm_", "dsymm_", "csymm_", "zsymm_", "chemm_", "zhemm_"):

@@ -899,6 +899,80 @@ int zsyrk_(const char* uplo, const char* trans, const int* n, const int* k, cons
   return f77_syrk(C64, "ZSYRK ", uplo, trans, n, k, alpha, a, lda, beta, c, ldc);
 }
 
+// ---- ?herk_ (blas/level3_impl.h:562-624) ------------------------------------------------
+
+static double read_real(int dtype, const void* p) {
+  return (dtype == F32 || dtype == C32) ? (double)*static_cast<const float*>(p) : *static_cast<const double*>(p);
+}
+
+int eigamd_herk_dev(int dtype, int uplo, int op, int64_t n, int64_t k, const void* alpha, const void* d_a, int64_t lda,
+                    const void* beta, void* d_c, int64_t ldc, void* stream) {
+  if (dtype != C32 && dtype != C64) return fail(EIGAMD_ERR_ARG, "herk is defined for the complex kinds");
+  if (uplo < 0 || uplo > 1 || (op != OP_N && op != OP_C) || n < 0 || k < 0 ||
+      lda < std::max<int64_t>(1, op == OP_N ? n : k) || ldc < std::max<int64_t>(1, n) || n > 0x7fffffff || k > 0x7fffffff)
+    return fail(EIGAMD_ERR_ARG, "invalid herk arguments");
+  if (n == 0) return EIGAMD_OK;
+  int rc = ensure_device();
+  if (rc != EIGAMD_OK) return rc;
+  HIP_TRY(herk_device(dtype, uplo == 0, op, n, k, read_real(dtype, alpha), d_a, lda, read_real(dtype, beta), d_c, ldc,
+                      static_cast<hipStream_t>(stream)));
+  return EIGAMD_OK;
+}
+
+static int herk_host_impl(int dtype, int uplo, int op, int64_t n, int64_t k, double alpha, const void* a, int64_t lda,
+                          double beta, void* c, int64_t ldc) {
+  int rc = ensure_device();
+  if (rc != EIGAMD_OK) return rc;
+  const int es = kElemSize[dtype];
+  const int64_t a_rows = op == OP_N ? n : k, a_cols = op == OP_N ? k : n;
+  const int64_t dlda = round_up(std::max<int64_t>(a_rows, 1), 16), dldc = round_up(n, 16);
+  Staging& st = staging();
+  std::lock_guard<std::mutex> lock(st.mu);
+  if ((rc = st.init()) != EIGAMD_OK) return rc;
+  if (k > 0 && (rc = st.reserve(0, (size_t)dlda * a_cols * es)) != EIGAMD_OK) return rc;
+  if ((rc = st.reserve(2, (size_t)dldc * n * es)) != EIGAMD_OK) return rc;
+  if (k > 0 && (rc = st.upload(st.buf[0], dlda, a, lda, a_rows, a_cols, es)) != EIGAMD_OK) return rc;
+  // the whole n x n window travels both ways; the kernels touch the uplo triangle only
+  if ((rc = st.upload(st.buf[2], dldc, c, ldc, n, n, es)) != EIGAMD_OK) return rc;
+  HIP_TRY(hipEventRecord(st.uploaded, st.h2d));
+  HIP_TRY(hipStreamWaitEvent(st.stream, st.uploaded, 0));
+  HIP_TRY(herk_device(dtype, uplo == 0, op, n, k, alpha, st.buf[0], dlda, beta, st.buf[2], dldc, st.stream));
+  HIP_TRY(hipEventRecord(st.computed, st.stream));
+  HIP_TRY(hipStreamWaitEvent(st.d2h, st.computed, 0));
+  return st.download(c, ldc, st.buf[2], dldc, n, n, es);
+}
+
+static int f77_herk(int dtype, const char* name, const char* uplo, const char* opc, const int* n, const int* k,
+                    const void* alpha, const void* a, const int* lda, const void* beta, void* c, const int* ldc) {
+  const int ul = uplo_of(*uplo), op = op_of(*opc);
+  int info = 0;                                                    // level3_impl.h:591-599
+  if (ul < 0) info = 1;
+  else if (op < 0 || op == OP_T) info = 2;
+  else if (*n < 0) info = 3;
+  else if (*k < 0) info = 4;
+  else if (*lda < std::max(1, op == OP_N ? *n : *k)) info = 7;
+  else if (*ldc < std::max(1, *n)) info = 10;
+  if (info) return xerbla_(name, &info, 6);
+  if (*n == 0) return 0;
+  const double al = read_real(dtype, alpha), be = read_real(dtype, beta);
+  if ((*k == 0 || al == 0.0) && be == 1.0) return 0;               // nothing to do: C keeps every bit
+  int rc = herk_host_impl(dtype, ul, op, *n, *k, al, a, *lda, be, c, *ldc);
+  if (rc != EIGAMD_OK) {
+    std::fprintf(stderr, "eigen_amd %s: %s\n", name, g_err.c_str());
+    std::abort();
+  }
+  return 0;
+}
+
+int cherk_(const char* uplo, const char* trans, const int* n, const int* k, const float* alpha, const float* a,
+           const int* lda, const float* beta, float* c, const int* ldc) {
+  return f77_herk(C32, "CHERK ", uplo, trans, n, k, alpha, a, lda, beta, c, ldc);
+}
+int zherk_(const char* uplo, const char* trans, const int* n, const int* k, const double* alpha, const double* a,
+           const int* lda, const double* beta, double* c, const int* ldc) {
+  return f77_herk(C64, "ZHERK ", uplo, trans, n, k, alpha, a, lda, beta, c, ldc);
+}
+
 // ---- ?symm_ / ?hemm_ (blas/level3_impl.h:245-353, :505-560) and ?trmm_ (:183-243) -------
 
 int eigamd_symm_dev(int dtype, int side, int uplo, int hermitian, int64_t m, int64_t n, const void* alpha, const void* d_a,

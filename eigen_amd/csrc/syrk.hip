@@ -70,4 +70,37 @@ hipError_t syrk_device(int kind, bool upper, int op, int64_t n, int64_t k, const
   return block(0, n, 0, n, upper ? 2 : 1);
 }
 
+namespace {
+// Imaginary part of the diagonal <- 0 (what blas/level3_impl.h:613-614, :621 do after the
+// Hermitian update).
+template <typename Z> __global__ void zero_diag_imag(Z* C, int64_t ldc, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) C[i + (int64_t)i * ldc].y = 0;
+}
+}  // namespace
+
+hipError_t herk_device(int kind, bool upper, int op, int64_t n, int64_t k, double alpha, const void* A, int64_t lda,
+                       double beta, void* C, int64_t ldc, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  if (kind != C32 && kind != C64) return hipErrorInvalidValue;
+  const bool product = k > 0 && alpha != 0.0;                  // level3_impl.h:617
+  if (!product && beta == 1.0) return hipSuccess;              // C is not touched at all
+  GemmCall g;
+  g.kind = kind;
+  g.m = n; g.n = n; g.k = product ? k : 0;
+  g.alpha[0] = alpha; g.alpha[1] = 0.0;
+  g.beta[0] = beta; g.beta[1] = 0.0;
+  if (op == OP_N) { g.opa = OP_N; g.opb = OP_C; }              // A (n x k) times A^H
+  else            { g.opa = OP_C; g.opb = OP_N; }              // A^H times A (A is k x n)
+  g.A = A; g.B = A; g.lda = lda; g.ldb = lda;
+  g.C = C; g.ldc = ldc;
+  g.tri = upper ? 2 : 1;
+  hipError_t e = launch_any(g, s);   // k == 0: the launcher runs the scale kernel on the triangle
+  if (e != hipSuccess) return e;
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  if (kind == C32) hipLaunchKernelGGL(zero_diag_imag<float2>, dim3(blocks), dim3(256), 0, s, (float2*)C, ldc, (int)n);
+  else hipLaunchKernelGGL(zero_diag_imag<double2>, dim3(blocks), dim3(256), 0, s, (double2*)C, ldc, (int)n);
+  return hipGetLastError();
+}
+
 }  // namespace eigamd

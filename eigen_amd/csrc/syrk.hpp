@@ -12,4 +12,10 @@ namespace eigamd {
 hipError_t syrk_device(int kind, bool upper, int op, int64_t n, int64_t k, const double alpha[2], const void* A,
                        int64_t lda, const double beta[2], void* C, int64_t ldc, hipStream_t s);
 
+// Hermitian rank-k update (complex kinds): C <- alpha * A * A^H + beta * C (op = OP_N) or
+// alpha * A^H * A + beta * C (op = OP_C) on one triangle, alpha and beta real, the imaginary part
+// of the diagonal set to zero; nothing is touched when there is no product and beta == 1.
+hipError_t herk_device(int kind, bool upper, int op, int64_t n, int64_t k, double alpha, const void* A, int64_t lda,
+                       double beta, void* C, int64_t ldc, hipStream_t s);
+
 }  // namespace eigamd

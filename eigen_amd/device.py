@@ -132,6 +132,21 @@ def syrk_dev(uplo, trans, alpha, a, beta, c, stream=None):
     return c
 
 
+def herk_dev(uplo, trans, alpha, a, beta, c, stream=None):
+    """c <- alpha * a * a^H + beta * c (trans 'N') or alpha * a^H * a + beta * c (trans 'C') on the
+    uplo triangle of the square complex DeviceMatrix c; alpha and beta real (``eigamd_herk_dev``)."""
+    if a.kind != c.kind:
+        raise ValueError("operands must share one scalar kind")
+    rdt = np.float32 if c.kind == _lib.C32 else np.float64
+    al, be = np.array([alpha], dtype=rdt), np.array([beta], dtype=rdt)
+    k = a.cols if trans.upper() == "N" else a.rows
+    rc = lib.eigamd_herk_dev(c.kind, "UL".index(uplo.upper()), _OPCODE[trans.upper()], c.rows, k,
+                             ctypes.c_void_p(al.ctypes.data), ctypes.c_void_p(a.ptr), a.ld,
+                             ctypes.c_void_p(be.ctypes.data), ctypes.c_void_p(c.ptr), c.ld, _stream_ptr(stream))
+    _lib.check(rc, "eigamd_herk_dev")
+    return c
+
+
 def symm_dev(side, uplo, alpha, a, b, beta, c, hermitian=False, stream=None):
     """c <- alpha * a * b + beta * c (side 'L') or alpha * b * a + beta * c (side 'R'), a symmetric
     (Hermitian if asked) and read through its uplo triangle only (``eigamd_symm_dev``)."""

@@ -191,6 +191,22 @@ int zsyrk_(const char* uplo, const char* trans, const int* n, const int* k, cons
 int eigamd_syrk_dev(int dtype, int uplo, int op, int64_t n, int64_t k, const void* alpha, const void* d_a, int64_t lda,
                     const void* beta, void* d_c, int64_t ldc, void* stream);
 
+/* ---- Hermitian rank-k update -----------------------------------------------------
+ *
+ * cherk_/zherk_ replace EIGEN_BLAS_FUNC(herk) (blas/level3_impl.h:562-624): C <- alpha A A^H +
+ * beta C (trans 'N') or alpha A^H A + beta C (trans 'C'; 'T' is an error) on the uplo triangle of
+ * the n x n matrix C, alpha and beta REAL (pointers to one float / double), the imaginary part of
+ * the diagonal set to zero; when there is no product (k == 0 or alpha == 0) and beta == 1 nothing
+ * is touched.  xerbla_ codes as ?syrk_.  (Eigen's own header binding for it is commented out,
+ * GeneralMatrixMatrixTriangular_BLAS.h:134-140: reached through the F77 ABI only.)
+ * eigamd_herk_dev: the same on matrices already in HBM (op is EIGAMD_OP_N or EIGAMD_OP_C). */
+int cherk_(const char* uplo, const char* trans, const int* n, const int* k, const float* alpha, const float* a,
+           const int* lda, const float* beta, float* c, const int* ldc);
+int zherk_(const char* uplo, const char* trans, const int* n, const int* k, const double* alpha, const double* a,
+           const int* lda, const double* beta, double* c, const int* ldc);
+int eigamd_herk_dev(int dtype, int uplo, int op, int64_t n, int64_t k, const void* alpha, const void* d_a, int64_t lda,
+                    const void* beta, void* d_c, int64_t ldc, void* stream);
+
 /* ---- products with a symmetric / Hermitian / triangular operand ------------------
  *
  * {s,d,c,z}symm_ and {c,z}hemm_ replace EIGEN_BLAS_FUNC(symm) / (hemm)

@@ -192,6 +192,36 @@ int netlib_chke_trsm(trsm_fn_t trsm, char letter) {
   return nfail;
 }
 
+/* HERK rows of ZCHKE / CCHKE (zblat3.f, error exits of ZHERK): 18 calls; trans 'T' is the
+ * invalid value of row 2 and 'C' takes the place of 'T' elsewhere. */
+typedef int (*herk_any_fn_t)(const char *, const char *, const int *, const int *, const void *, const void *, const int *,
+                             const void *, void *, const int *);
+int netlib_chke_herk(herk_any_fn_t herk, char letter) {
+  static const struct { int infot; char ul, tr; int n, k, lda, ldc; } rows[] = {
+      {1, '/', 'N', 0, 0, 1, 1},  {2, 'U', 'T', 0, 0, 1, 1},
+      {3, 'U', 'N', -1, 0, 1, 1}, {3, 'U', 'C', -1, 0, 1, 1}, {3, 'L', 'N', -1, 0, 1, 1}, {3, 'L', 'C', -1, 0, 1, 1},
+      {4, 'U', 'N', 0, -1, 1, 1}, {4, 'U', 'C', 0, -1, 1, 1}, {4, 'L', 'N', 0, -1, 1, 1}, {4, 'L', 'C', 0, -1, 1, 1},
+      {7, 'U', 'N', 2, 0, 1, 2},  {7, 'U', 'C', 0, 2, 1, 1},  {7, 'L', 'N', 2, 0, 1, 2},  {7, 'L', 'C', 0, 2, 1, 1},
+      {10, 'U', 'N', 2, 0, 2, 1}, {10, 'U', 'C', 2, 0, 1, 1}, {10, 'L', 'N', 2, 0, 2, 1}, {10, 'L', 'C', 2, 0, 1, 1},
+  };
+  double a[8] = {0}, c[8] = {0}, alpha = 1, beta = 2;
+  float alphaf = 1, betaf = 2;
+  const int single = letter == 'C';
+  char want[8];
+  snprintf(want, sizeof want, "%cHERK ", letter);
+  int nfail = 0;
+  for (unsigned r = 0; r < sizeof rows / sizeof rows[0]; ++r) {
+    netlib_xerbla_count = 0;
+    netlib_xerbla_info = 0;
+    herk(&rows[r].ul, &rows[r].tr, &rows[r].n, &rows[r].k, single ? (void *)&alphaf : (void *)&alpha, a, &rows[r].lda,
+         single ? (void *)&betaf : (void *)&beta, c, &rows[r].ldc);
+    if (netlib_xerbla_count != 1 || netlib_xerbla_info != rows[r].infot || strncmp(netlib_xerbla_name, want, 6) != 0)
+      nfail += 1;
+  }
+  netlib_xerbla_count = 0;
+  return nfail;
+}
+
 /* SYRK rows of ?CHKE (dblat3.f:2262-2300): 18 calls. */
 int netlib_chke_syrk(syrk_fn_t syrk, char letter) {
   static const struct { int infot; char ul, tr; int n, k, lda, ldc; } rows[] = {

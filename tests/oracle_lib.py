@@ -301,6 +301,48 @@ def syrk_operands(kind, uplo, trans, n, k, seed, pad=0):
     return a, c
 
 
+def run_netlib_chk4_herk(kind, herk_fn, params):
+    """Restated HERK rows of ZCHK4 / CCHK4 over `herk_fn` (ctypes function, ?herk_ signature)."""
+    real = ctypes.c_float if kind == 2 else ctypes.c_double
+    idim = (ctypes.c_int * len(params["idim"]))(*params["idim"])
+    alf = (real * len(params["alf"]))(*params["alf"])
+    bet = (real * len(params["bet"]))(*params["bet"])
+    rep = NetlibReport()
+    f = getattr(oracle, "netlib_chk4_herk_" + SUFFIX[kind])
+    f(ctypes.cast(herk_fn, ctypes.c_void_p), len(params["idim"]), idim, len(params["alf"]) // 2, alf,
+      len(params["bet"]) // 2, bet, ctypes.byref(rep))
+    return rep
+
+
+def run_netlib_chke_herk(kind, herk_fn):
+    return oracle.netlib_chke_herk(ctypes.cast(herk_fn, ctypes.c_void_p), ctypes.c_char("SDCZ"[kind].encode()))
+
+
+def oracle_herk(kind):
+    return getattr(oracle, "oracle_herk_" + SUFFIX[kind])
+
+
+def call_f77_herk(fn, uplo, trans, n, k, alpha, a, lda, beta, c, ldc):
+    """Call any function with the F77 ?herk_ signature on numpy buffers (alpha, beta real)."""
+    rdt = np.float32 if c.dtype == np.complex64 else np.float64
+    al, be = np.array([alpha], dtype=rdt), np.array([beta], dtype=rdt)
+    ci = lambda v: ctypes.byref(ctypes.c_int(int(v)))
+    cs = lambda ch: ctypes.c_char_p(ch.encode())
+    fn(cs(uplo), cs(trans), ci(n), ci(k), _vp(al), _vp(a), ci(lda), _vp(be), _vp(c), ci(ldc))
+    return c
+
+
+def herk_operands(kind, uplo, trans, n, k, seed, pad=0):
+    """A (n x k, or k x n for trans 'C') and C (n x n) from the library's generator; the triangle
+    of C that ?herk_ must not touch holds -1e10, and so does the imaginary part of C's diagonal
+    (it must be ignored, as ZMAKE 'HE' of the Netlib tester arranges)."""
+    a, c = syrk_operands(kind, uplo, "N" if trans == "N" else "T", n, k, seed, pad)
+    if n:
+        i = np.arange(n)
+        c[i, i] = c[i, i].real - 1.0e10j
+    return a, c
+
+
 def run_netlib_chk2(kind, fn, herm, params):
     """Restated ?CHK2 (SYMM; HEMM when herm) over `fn` (ctypes function, ?symm_ signature)."""
     real = ctypes.c_float if kind in (0, 2) else ctypes.c_double
