@@ -82,6 +82,12 @@ for _name in ("cherk_", "zherk_"):
     _f.argtypes = [ctypes.c_char_p] * 2 + [_i32p, _i32p, _vp, _vp, _i32p, _vp, _vp, _i32p]
 lib.eigamd_herk_dev.restype = ctypes.c_int
 lib.eigamd_herk_dev.argtypes = [ctypes.c_int] * 3 + [_i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp]
+for _name in ("ssyr2k_", "dsyr2k_", "csyr2k_", "zsyr2k_", "cher2k_", "zher2k_"):
+    _f = getattr(lib, _name)
+    _f.restype = ctypes.c_int
+    _f.argtypes = [ctypes.c_char_p] * 2 + [_i32p, _i32p, _vp, _vp, _i32p, _vp, _i32p, _vp, _vp, _i32p]
+lib.eigamd_syr2k_dev.restype = ctypes.c_int
+lib.eigamd_syr2k_dev.argtypes = [ctypes.c_int] * 4 + [_i64, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp]
 lib.eigamd_syrk_dev.restype = ctypes.c_int
 lib.eigamd_syrk_dev.argtypes = [ctypes.c_int] * 3 + [_i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp]
 for _name in ("ssymm_", "dsymm_", "csymm_", "zsymm_", "chemm_", "zhemm_"):

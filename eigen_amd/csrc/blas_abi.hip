@@ -973,6 +973,95 @@ int zherk_(const char* uplo, const char* trans, const int* n, const int* k, cons
   return f77_herk(C64, "ZHERK ", uplo, trans, n, k, alpha, a, lda, beta, c, ldc);
 }
 
+// ---- ?syr2k_ / ?her2k_ (blas/level3_impl.h:435-501, :626-700) -----------------------------
+
+int eigamd_syr2k_dev(int dtype, int uplo, int op, int hermitian, int64_t n, int64_t k, const void* alpha, const void* d_a,
+                     int64_t lda, const void* d_b, int64_t ldb, const void* beta, void* d_c, int64_t ldc, void* stream) {
+  if (dtype < 0 || dtype > 3) return fail(EIGAMD_ERR_ARG, "dtype out of range");
+  if (hermitian && dtype < C32) return fail(EIGAMD_ERR_ARG, "her2k is defined for the complex kinds");
+  const bool op_ok = op == OP_N || (hermitian ? op == OP_C : op == OP_T);
+  const int64_t need = std::max<int64_t>(1, op == OP_N ? n : k);
+  if (uplo < 0 || uplo > 1 || !op_ok || n < 0 || k < 0 || lda < need || ldb < need || ldc < std::max<int64_t>(1, n) ||
+      n > 0x7fffffff || k > 0x7fffffff)
+    return fail(EIGAMD_ERR_ARG, "invalid syr2k arguments");
+  if (n == 0) return EIGAMD_OK;
+  int rc = ensure_device();
+  if (rc != EIGAMD_OK) return rc;
+  double al[2], be[2];
+  read_scalar(dtype, alpha, al);
+  read_scalar(dtype, beta, be);
+  if (hermitian && be[1] != 0.0) return fail(EIGAMD_ERR_ARG, "her2k takes a real beta");
+  HIP_TRY(syr2k_device(dtype, uplo == 0, op, hermitian != 0, n, k, al, d_a, lda, d_b, ldb, be, d_c, ldc,
+                       static_cast<hipStream_t>(stream)));
+  return EIGAMD_OK;
+}
+
+static int syr2k_host_impl(int dtype, int uplo, int op, bool herm, int64_t n, int64_t k, const double alpha[2], const void* a,
+                           int64_t lda, const void* b, int64_t ldb, const double beta[2], void* c, int64_t ldc) {
+  int rc = ensure_device();
+  if (rc != EIGAMD_OK) return rc;
+  const int es = kElemSize[dtype];
+  const int64_t rows = op == OP_N ? n : k, cols = op == OP_N ? k : n;
+  const int64_t dld = round_up(std::max<int64_t>(rows, 1), 16), dldc = round_up(n, 16);
+  Staging& st = staging();
+  std::lock_guard<std::mutex> lock(st.mu);
+  if ((rc = st.init()) != EIGAMD_OK) return rc;
+  if (k > 0 && (rc = st.reserve(0, (size_t)dld * cols * es)) != EIGAMD_OK) return rc;
+  if (k > 0 && (rc = st.reserve(1, (size_t)dld * cols * es)) != EIGAMD_OK) return rc;
+  if ((rc = st.reserve(2, (size_t)dldc * n * es)) != EIGAMD_OK) return rc;
+  if (k > 0 && (rc = st.upload(st.buf[0], dld, a, lda, rows, cols, es)) != EIGAMD_OK) return rc;
+  if (k > 0 && (rc = st.upload(st.buf[1], dld, b, ldb, rows, cols, es)) != EIGAMD_OK) return rc;
+  if ((rc = st.upload(st.buf[2], dldc, c, ldc, n, n, es)) != EIGAMD_OK) return rc;
+  HIP_TRY(hipEventRecord(st.uploaded, st.h2d));
+  HIP_TRY(hipStreamWaitEvent(st.stream, st.uploaded, 0));
+  HIP_TRY(syr2k_device(dtype, uplo == 0, op, herm, n, k, alpha, st.buf[0], dld, st.buf[1], dld, beta, st.buf[2], dldc, st.stream));
+  HIP_TRY(hipEventRecord(st.computed, st.stream));
+  HIP_TRY(hipStreamWaitEvent(st.d2h, st.computed, 0));
+  return st.download(c, ldc, st.buf[2], dldc, n, n, es);
+}
+
+static int f77_syr2k(int dtype, bool herm, const char* name, const char* uplo, const char* opc, const int* n, const int* k,
+                     const void* alpha, const void* a, const int* lda, const void* b, const int* ldb, const void* beta,
+                     void* c, const int* ldc) {
+  const int ul = uplo_of(*uplo);
+  int op = op_of(*opc);
+  int info = 0;                                                    // level3_impl.h:450-459 / :642-651
+  if (ul < 0) info = 1;
+  else if (op < 0 || (herm ? op == OP_T : (dtype >= C32 && op == OP_C))) info = 2;
+  else if (*n < 0) info = 3;
+  else if (*k < 0) info = 4;
+  else if (*lda < std::max(1, op == OP_N ? *n : *k)) info = 7;
+  else if (*ldb < std::max(1, op == OP_N ? *n : *k)) info = 9;
+  else if (*ldc < std::max(1, *n)) info = 12;
+  if (info) return xerbla_(name, &info, 6);
+  if (!herm && op == OP_C) op = OP_T;   // real kinds: 'C' is 'T'
+  const int ret = herm ? 1 : (*k == 0 ? 1 : 0);                    // what the reference returns (:474-475, :699)
+  if (*n == 0) return ret;
+  double al[2], be[2];
+  read_scalar(dtype, alpha, al);
+  if (herm) { be[0] = read_real(dtype, beta); be[1] = 0.0; }
+  else read_scalar(dtype, beta, be);
+  if ((*k == 0 || (al[0] == 0.0 && al[1] == 0.0)) && be[0] == 1.0 && be[1] == 0.0) return ret;
+  int rc = syr2k_host_impl(dtype, ul, op, herm, *n, *k, al, a, *lda, b, *ldb, be, c, *ldc);
+  if (rc != EIGAMD_OK) {
+    std::fprintf(stderr, "eigen_amd %s: %s\n", name, g_err.c_str());
+    std::abort();
+  }
+  return ret;
+}
+
+#define EIGAMD_SYR2K_ENTRY(fn, T, kind, herm, name)                                                                       \
+  int fn(const char* uplo, const char* trans, const int* n, const int* k, const T* alpha, const T* a, const int* lda,      \
+         const T* b, const int* ldb, const T* beta, T* c, const int* ldc) {                                                \
+    return f77_syr2k(kind, herm, name, uplo, trans, n, k, alpha, a, lda, b, ldb, beta, c, ldc);                            \
+  }
+EIGAMD_SYR2K_ENTRY(ssyr2k_, float, F32, false, "SSYR2K")
+EIGAMD_SYR2K_ENTRY(dsyr2k_, double, F64, false, "DSYR2K")
+EIGAMD_SYR2K_ENTRY(csyr2k_, float, C32, false, "CSYR2K")
+EIGAMD_SYR2K_ENTRY(zsyr2k_, double, C64, false, "ZSYR2K")
+EIGAMD_SYR2K_ENTRY(cher2k_, float, C32, true, "CHER2K")
+EIGAMD_SYR2K_ENTRY(zher2k_, double, C64, true, "ZHER2K")
+
 // ---- ?symm_ / ?hemm_ (blas/level3_impl.h:245-353, :505-560) and ?trmm_ (:183-243) -------
 
 int eigamd_symm_dev(int dtype, int side, int uplo, int hermitian, int64_t m, int64_t n, const void* alpha, const void* d_a,

@@ -103,4 +103,46 @@ hipError_t herk_device(int kind, bool upper, int op, int64_t n, int64_t k, doubl
   return hipGetLastError();
 }
 
+// Rank-2k updates (EIGEN_BLAS_FUNC(syr2k) / (her2k), blas/level3_impl.h:435-501, :626-700):
+//   C <- alpha op(A) op(B)^T + alpha op(B) op(A)^T + beta C             (symmetric)
+//   C <- alpha op(A) op(B)^H + conj(alpha) op(B) op(A)^H + beta C       (Hermitian, beta real)
+// on one triangle of C.  The reference writes them as two dense product expressions assigned to
+// a triangular view; here they are two launches of the triangular-destination GEMM, the second
+// accumulating onto the first.
+hipError_t syr2k_device(int kind, bool upper, int op, bool herm, int64_t n, int64_t k, const double alpha[2], const void* A,
+                        int64_t lda, const void* B, int64_t ldb, const double beta[2], void* C, int64_t ldc, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  if (herm && kind != C32 && kind != C64) return hipErrorInvalidValue;
+  const bool product = k > 0 && (alpha[0] != 0.0 || alpha[1] != 0.0);
+  const bool beta_one = beta[0] == 1.0 && beta[1] == 0.0;
+  if (!product && beta_one) return hipSuccess;
+  const bool notrans = op == OP_N;
+  const int tr = herm ? OP_C : OP_T;
+  GemmCall g;
+  g.kind = kind;
+  g.m = n; g.n = n; g.k = product ? k : 0;
+  g.alpha[0] = alpha[0]; g.alpha[1] = alpha[1];
+  g.beta[0] = beta[0]; g.beta[1] = herm ? 0.0 : beta[1];
+  g.opa = notrans ? OP_N : tr;
+  g.opb = notrans ? tr : OP_N;
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb;
+  g.C = C; g.ldc = ldc;
+  g.tri = upper ? 2 : 1;
+  hipError_t e = launch_any(g, s);   // k == 0: the scale kernel on the triangle
+  if (e != hipSuccess) return e;
+  if (product) {
+    g.A = B; g.lda = ldb; g.B = A; g.ldb = lda;
+    if (herm) g.alpha[1] = -alpha[1];
+    g.beta[0] = 1.0; g.beta[1] = 0.0;
+    e = launch_any(g, s);
+    if (e != hipSuccess) return e;
+  }
+  if (herm) {
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (kind == C32) hipLaunchKernelGGL(zero_diag_imag<float2>, dim3(blocks), dim3(256), 0, s, (float2*)C, ldc, (int)n);
+    else hipLaunchKernelGGL(zero_diag_imag<double2>, dim3(blocks), dim3(256), 0, s, (double2*)C, ldc, (int)n);
+  }
+  return hipGetLastError();
+}
+
 }  // namespace eigamd

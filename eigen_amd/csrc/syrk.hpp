@@ -18,4 +18,10 @@ hipError_t syrk_device(int kind, bool upper, int op, int64_t n, int64_t k, const
 hipError_t herk_device(int kind, bool upper, int op, int64_t n, int64_t k, double alpha, const void* A, int64_t lda,
                        double beta, void* C, int64_t ldc, hipStream_t s);
 
+// Rank-2k update on one triangle of the n x n matrix C: alpha op(A) op(B)^T + alpha op(B) op(A)^T +
+// beta C, or with `herm` (complex kinds, beta real) alpha op(A) op(B)^H + conj(alpha) op(B) op(A)^H +
+// beta C with the diagonal's imaginary part set to zero.  op = OP_N: A, B are n x k; otherwise k x n.
+hipError_t syr2k_device(int kind, bool upper, int op, bool herm, int64_t n, int64_t k, const double alpha[2], const void* A,
+                        int64_t lda, const void* B, int64_t ldb, const double beta[2], void* C, int64_t ldc, hipStream_t s);
+
 }  // namespace eigamd

@@ -147,6 +147,19 @@ def herk_dev(uplo, trans, alpha, a, beta, c, stream=None):
     return c
 
 
+def syr2k_dev(uplo, trans, alpha, a, b, beta, c, hermitian=False, stream=None):
+    """c <- alpha * op(a) * op(b)^T + alpha * op(b) * op(a)^T + beta * c on the uplo triangle of c, or
+    the Hermitian form (^H, conj(alpha) in the second term, beta real) (``eigamd_syr2k_dev``)."""
+    dt = _NP_OF_KIND[c.kind]
+    al, be = np.array([alpha], dtype=dt), np.array([beta], dtype=dt)
+    k = a.cols if trans.upper() == "N" else a.rows
+    rc = lib.eigamd_syr2k_dev(c.kind, "UL".index(uplo.upper()), _OPCODE[trans.upper()], int(bool(hermitian)), c.rows, k,
+                              ctypes.c_void_p(al.ctypes.data), ctypes.c_void_p(a.ptr), a.ld, ctypes.c_void_p(b.ptr), b.ld,
+                              ctypes.c_void_p(be.ctypes.data), ctypes.c_void_p(c.ptr), c.ld, _stream_ptr(stream))
+    _lib.check(rc, "eigamd_syr2k_dev")
+    return c
+
+
 def symm_dev(side, uplo, alpha, a, b, beta, c, hermitian=False, stream=None):
     """c <- alpha * a * b + beta * c (side 'L') or alpha * b * a + beta * c (side 'R'), a symmetric
     (Hermitian if asked) and read through its uplo triangle only (``eigamd_symm_dev``)."""

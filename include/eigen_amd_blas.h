@@ -207,6 +207,33 @@ int zherk_(const char* uplo, const char* trans, const int* n, const int* k, cons
 int eigamd_herk_dev(int dtype, int uplo, int op, int64_t n, int64_t k, const void* alpha, const void* d_a, int64_t lda,
                     const void* beta, void* d_c, int64_t ldc, void* stream);
 
+/* ---- rank-2k updates ----------------------------------------------------------------
+ *
+ * {s,d,c,z}syr2k_ replace EIGEN_BLAS_FUNC(syr2k) (blas/level3_impl.h:435-501): C <- alpha A B^T +
+ * alpha B A^T + beta C (trans 'N', A and B n x k) or alpha A^T B + alpha B^T A + beta C (trans 'T';
+ * 'C' too for the real kinds, an error for the complex ones) on the uplo triangle of C.
+ * cher2k_/zher2k_ replace EIGEN_BLAS_FUNC(her2k) (:626-700): alpha A B^H + conj(alpha) B A^H + beta C
+ * (trans 'N') or alpha A^H B + conj(alpha) B^H A + beta C (trans 'C'), beta REAL (a pointer to one
+ * float / double), the imaginary part of the diagonal zero on return.  xerbla_ codes 1 uplo, 2 trans,
+ * 3 n, 4 k, 7 lda, 9 ldb, 12 ldc; return values as the reference's (?syr2k_: 1 when k == 0, else 0;
+ * ?her2k_: 1).  Not bound by Eigen's headers: reached through the F77 ABI only.
+ * eigamd_syr2k_dev: both on matrices already in HBM; alpha and beta point to scalars of kind `dtype`
+ * (the imaginary part of beta must be zero when `hermitian`). */
+int ssyr2k_(const char* uplo, const char* trans, const int* n, const int* k, const float* alpha, const float* a, const int* lda,
+            const float* b, const int* ldb, const float* beta, float* c, const int* ldc);
+int dsyr2k_(const char* uplo, const char* trans, const int* n, const int* k, const double* alpha, const double* a,
+            const int* lda, const double* b, const int* ldb, const double* beta, double* c, const int* ldc);
+int csyr2k_(const char* uplo, const char* trans, const int* n, const int* k, const float* alpha, const float* a, const int* lda,
+            const float* b, const int* ldb, const float* beta, float* c, const int* ldc);
+int zsyr2k_(const char* uplo, const char* trans, const int* n, const int* k, const double* alpha, const double* a,
+            const int* lda, const double* b, const int* ldb, const double* beta, double* c, const int* ldc);
+int cher2k_(const char* uplo, const char* trans, const int* n, const int* k, const float* alpha, const float* a, const int* lda,
+            const float* b, const int* ldb, const float* beta, float* c, const int* ldc);
+int zher2k_(const char* uplo, const char* trans, const int* n, const int* k, const double* alpha, const double* a,
+            const int* lda, const double* b, const int* ldb, const double* beta, double* c, const int* ldc);
+int eigamd_syr2k_dev(int dtype, int uplo, int op, int hermitian, int64_t n, int64_t k, const void* alpha, const void* d_a,
+                     int64_t lda, const void* d_b, int64_t ldb, const void* beta, void* d_c, int64_t ldc, void* stream);
+
 /* ---- products with a symmetric / Hermitian / triangular operand ------------------
  *
  * {s,d,c,z}symm_ and {c,z}hemm_ replace EIGEN_BLAS_FUNC(symm) / (hemm)

@@ -222,6 +222,38 @@ int netlib_chke_herk(herk_any_fn_t herk, char letter) {
   return nfail;
 }
 
+/* SYR2K rows of ?CHKE (dblat3.f:2314-2390) and HER2K rows of ZCHKE: 22 calls; for HER2K 'T' is
+ * the invalid trans of row 2 and 'C' takes the place of 'T' elsewhere, beta real. */
+typedef int (*r2k_any_fn_t)(const char *, const char *, const int *, const int *, const void *, const void *, const int *,
+                            const void *, const int *, const void *, void *, const int *);
+int netlib_chke_r2k(r2k_any_fn_t r2k, char letter, int herm) {
+  const char T = herm ? 'C' : 'T';
+  const struct { int infot; char ul, tr; int n, k, lda, ldb, ldc; } rows[] = {
+      {1, '/', 'N', 0, 0, 1, 1, 1},  {2, 'U', (char)(herm ? 'T' : '/'), 0, 0, 1, 1, 1},
+      {3, 'U', 'N', -1, 0, 1, 1, 1}, {3, 'U', T, -1, 0, 1, 1, 1}, {3, 'L', 'N', -1, 0, 1, 1, 1}, {3, 'L', T, -1, 0, 1, 1, 1},
+      {4, 'U', 'N', 0, -1, 1, 1, 1}, {4, 'U', T, 0, -1, 1, 1, 1}, {4, 'L', 'N', 0, -1, 1, 1, 1}, {4, 'L', T, 0, -1, 1, 1, 1},
+      {7, 'U', 'N', 2, 0, 1, 1, 2},  {7, 'U', T, 0, 2, 1, 1, 1},  {7, 'L', 'N', 2, 0, 1, 1, 2},  {7, 'L', T, 0, 2, 1, 1, 1},
+      {9, 'U', 'N', 2, 0, 2, 1, 2},  {9, 'U', T, 0, 2, 2, 1, 1},  {9, 'L', 'N', 2, 0, 2, 1, 2},  {9, 'L', T, 0, 2, 2, 1, 1},
+      {12, 'U', 'N', 2, 0, 2, 2, 1}, {12, 'U', T, 2, 0, 1, 1, 1}, {12, 'L', 'N', 2, 0, 2, 2, 1}, {12, 'L', T, 2, 0, 1, 1, 1},
+  };
+  double a[8] = {0}, b[8] = {0}, c[8] = {0}, alpha[2] = {1, 0}, beta[2] = {2, 0};
+  float alphaf[2] = {1, 0}, betaf[2] = {2, 0};
+  const int single = letter == 'S' || letter == 'C';
+  char want[8];
+  snprintf(want, sizeof want, "%c%s", letter, herm ? "HER2K" : "SYR2K");
+  int nfail = 0;
+  for (unsigned r = 0; r < sizeof rows / sizeof rows[0]; ++r) {
+    netlib_xerbla_count = 0;
+    netlib_xerbla_info = 0;
+    r2k(&rows[r].ul, &rows[r].tr, &rows[r].n, &rows[r].k, single ? (void *)alphaf : (void *)alpha, a, &rows[r].lda, b,
+        &rows[r].ldb, single ? (void *)betaf : (void *)beta, c, &rows[r].ldc);
+    if (netlib_xerbla_count != 1 || netlib_xerbla_info != rows[r].infot || strncmp(netlib_xerbla_name, want, 6) != 0)
+      nfail += 1;
+  }
+  netlib_xerbla_count = 0;
+  return nfail;
+}
+
 /* SYRK rows of ?CHKE (dblat3.f:2262-2300): 18 calls. */
 int netlib_chke_syrk(syrk_fn_t syrk, char letter) {
   static const struct { int infot; char ul, tr; int n, k, lda, ldc; } rows[] = {

@@ -343,6 +343,56 @@ def herk_operands(kind, uplo, trans, n, k, seed, pad=0):
     return a, c
 
 
+def run_netlib_chk5(kind, fn, herm, params):
+    """Restated ?CHK5 (SYR2K; HER2K when herm) over `fn` (ctypes function, ?syr2k_ / ?her2k_ signature)."""
+    real = ctypes.c_float if kind in (0, 2) else ctypes.c_double
+    idim = (ctypes.c_int * len(params["idim"]))(*params["idim"])
+    alf = (real * len(params["alf"]))(*params["alf"])
+    bet = (real * len(params["bet"]))(*params["bet"])
+    per = 2 if params["cplx"] else 1
+    rep = NetlibReport()
+    f = getattr(oracle, "netlib_chk5_" + SUFFIX[kind])
+    f(ctypes.cast(fn, ctypes.c_void_p), int(herm), len(params["idim"]), idim, len(params["alf"]) // per, alf,
+      len(params["bet"]) // per, bet, ctypes.byref(rep))
+    return rep
+
+
+def run_netlib_chke_r2k(kind, fn, herm):
+    return oracle.netlib_chke_r2k(ctypes.cast(fn, ctypes.c_void_p), ctypes.c_char("SDCZ"[kind].encode()), int(herm))
+
+
+def oracle_r2k(kind, herm):
+    return getattr(oracle, ("oracle_her2k_" if herm else "oracle_syr2k_") + SUFFIX[kind])
+
+
+def call_f77_r2k(fn, herm, uplo, trans, n, k, alpha, a, lda, b, ldb, beta, c, ldc):
+    """Call any function with the F77 ?syr2k_ / ?her2k_ signature (beta real for her2k)."""
+    al = np.array([alpha], dtype=c.dtype)
+    be = np.array([beta], dtype=(np.float32 if c.dtype == np.complex64 else np.float64) if herm else c.dtype)
+    ci = lambda v: ctypes.byref(ctypes.c_int(int(v)))
+    cs = lambda ch: ctypes.c_char_p(ch.encode())
+    fn.restype = ctypes.c_int
+    return fn(cs(uplo), cs(trans), ci(n), ci(k), _vp(al), _vp(a), ci(lda), _vp(b), ci(ldb), _vp(be), _vp(c), ci(ldc))
+
+
+def r2k_operands(kind, herm, uplo, trans, n, k, seed, pad=0):
+    """A, B (n x k, or k x n for trans != 'N') and C (n x n); the triangle of C that must not be
+    touched holds -1e10, and for the Hermitian form so does the imaginary part of C's diagonal."""
+    import eigen_amd
+    dt = DTYPES[kind]
+    ar, ac = (n, k) if trans == "N" else (k, n)
+    a = eigen_amd.fill_uniform_host(dt, ar, ac, seed, ld=ar + pad)
+    b = eigen_amd.fill_uniform_host(dt, ar, ac, seed + 7, ld=ar + pad)
+    c = eigen_amd.fill_uniform_host(dt, n, n, seed + 1, ld=n + pad)
+    if n:
+        i, j = np.indices((n, n))
+        c[(i > j) if uplo == "U" else (i < j)] = -1.0e10
+        if herm:
+            d = np.arange(n)
+            c[d, d] = c[d, d].real - 1.0e10j
+    return a, b, c
+
+
 def run_netlib_chk2(kind, fn, herm, params):
     """Restated ?CHK2 (SYMM; HEMM when herm) over `fn` (ctypes function, ?symm_ signature)."""
     real = ctypes.c_float if kind in (0, 2) else ctypes.c_double
