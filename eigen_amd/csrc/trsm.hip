@@ -23,14 +23,23 @@ namespace eigamd {
 
 namespace {
 
-constexpr int kNB = 128;       // diagonal block
+constexpr int kSmallNB = 128;  // diagonal block; kLargeNB where the GEMM tile allows it (real kinds)
+constexpr int kLargeNB = 256;
 constexpr int kInvCols = 32;   // columns of the inverse one workgroup owns
 
-// The in-place products below rely on one GEMM tile covering the whole block extent.
-static_assert(Geometry<F32>::BM >= kNB && Geometry<F32>::BN >= kNB, "tile smaller than the trsm block");
-static_assert(Geometry<F64>::BM >= kNB && Geometry<F64>::BN >= kNB, "tile smaller than the trsm block");
-static_assert(Geometry<C32>::BM >= kNB && Geometry<C32>::BN >= kNB, "tile smaller than the trsm block");
-static_assert(Geometry<C64>::BM >= kNB && Geometry<C64>::BN >= kNB, "tile smaller than the trsm block");
+// The in-place products below rely on one GEMM tile covering the whole block extent: along m
+// (tile extent BM) for a left-side solve, along n (BN) for a right-side one.  A 256-wide block
+// halves the number of leaf products and makes them whole tiles of the f64 / f32 kernels
+// (m = 128 leaves ran in the bounds-checked instantiation, a fifth of a dtrsm's time).
+static_assert(Geometry<F32>::BM >= kSmallNB && Geometry<F32>::BN >= kSmallNB, "tile smaller than the trsm block");
+static_assert(Geometry<F64>::BM >= kSmallNB && Geometry<F64>::BN >= kSmallNB, "tile smaller than the trsm block");
+static_assert(Geometry<C32>::BM >= kSmallNB && Geometry<C32>::BN >= kSmallNB, "tile smaller than the trsm block");
+static_assert(Geometry<C64>::BM >= kSmallNB && Geometry<C64>::BN >= kSmallNB, "tile smaller than the trsm block");
+inline int block_extent(int kind, bool left) {
+  if (kind == F64) return (left ? Geometry<F64>::BM : Geometry<F64>::BN) >= kLargeNB ? kLargeNB : kSmallNB;
+  if (kind == F32) return (left ? Geometry<F32>::BM : Geometry<F32>::BN) >= kLargeNB ? kLargeNB : kSmallNB;
+  return kSmallNB;
+}
 
 template <typename R> struct Cplx {
   R x, y;
@@ -64,9 +73,10 @@ template <> struct One<Cplx<double>> { static __device__ Cplx<double> v() { retu
 // a lower one.  grid = (kNB / kInvCols, number of blocks); a workgroup owns 32 columns of
 // one inverse in LDS and walks down the rows 32 at a time: first the part of the inner
 // products that needs finished rows only, then the 32 x 32 triangle on the diagonal.
-template <typename T>
+template <typename T, int NB>
 __global__ void __launch_bounds__(256) trtri_blocks(const T* __restrict__ A, int64_t lda, int na, int upper, int unit,
                                                     T* __restrict__ X) {
+  constexpr int kNB = NB;   // block extent of this instantiation
   __shared__ T s_x[kInvCols][kNB + 1];
   __shared__ T s_acc[kInvCols][kInvCols + 1];
   __shared__ T s_d[kInvCols][kInvCols + 1];  // s_d[k - i0][i - i0] = L(i, k) of the diagonal 32 x 32
@@ -181,6 +191,7 @@ hipError_t trsm_device(int kind, bool left, bool upper, int op, bool unit, int64
   if (m <= 0 || n <= 0) return hipSuccess;
   const int es = kElem[kind];
   const int64_t na = left ? m : n;
+  const int64_t kNB = block_extent(kind, left);
   const int64_t nblk = (na + kNB - 1) / kNB;
   const char* Ab = static_cast<const char*>(A);
   char* Bb = static_cast<char*>(B);
@@ -204,23 +215,32 @@ hipError_t trsm_device(int kind, bool left, bool upper, int op, bool unit, int64
   } else {
     TR_TRY(hipStreamWaitEvent(s, sc.done, 0));
   }
-  const dim3 grid(kNB / kInvCols, (unsigned)nblk);
+  const dim3 grid((unsigned)(kNB / kInvCols), (unsigned)nblk);
+  const int up = upper ? 1 : 0, un = unit ? 1 : 0;
   switch (kind) {
     case F32:
-      hipLaunchKernelGGL(trtri_blocks<float>, grid, dim3(256), 0, s, static_cast<const float*>(A), lda, (int)na, upper ? 1 : 0,
-                         unit ? 1 : 0, static_cast<float*>(sc.buf));
+      if (kNB == kLargeNB)
+        hipLaunchKernelGGL((trtri_blocks<float, kLargeNB>), grid, dim3(256), 0, s, static_cast<const float*>(A), lda, (int)na, up,
+                           un, static_cast<float*>(sc.buf));
+      else
+        hipLaunchKernelGGL((trtri_blocks<float, kSmallNB>), grid, dim3(256), 0, s, static_cast<const float*>(A), lda, (int)na, up,
+                           un, static_cast<float*>(sc.buf));
       break;
     case F64:
-      hipLaunchKernelGGL(trtri_blocks<double>, grid, dim3(256), 0, s, static_cast<const double*>(A), lda, (int)na,
-                         upper ? 1 : 0, unit ? 1 : 0, static_cast<double*>(sc.buf));
+      if (kNB == kLargeNB)
+        hipLaunchKernelGGL((trtri_blocks<double, kLargeNB>), grid, dim3(256), 0, s, static_cast<const double*>(A), lda, (int)na,
+                           up, un, static_cast<double*>(sc.buf));
+      else
+        hipLaunchKernelGGL((trtri_blocks<double, kSmallNB>), grid, dim3(256), 0, s, static_cast<const double*>(A), lda, (int)na,
+                           up, un, static_cast<double*>(sc.buf));
       break;
     case C32:
-      hipLaunchKernelGGL(trtri_blocks<Cplx<float>>, grid, dim3(256), 0, s, static_cast<const Cplx<float>*>(A), lda, (int)na,
-                         upper ? 1 : 0, unit ? 1 : 0, static_cast<Cplx<float>*>(sc.buf));
+      hipLaunchKernelGGL((trtri_blocks<Cplx<float>, kSmallNB>), grid, dim3(256), 0, s, static_cast<const Cplx<float>*>(A), lda,
+                         (int)na, up, un, static_cast<Cplx<float>*>(sc.buf));
       break;
     default:
-      hipLaunchKernelGGL(trtri_blocks<Cplx<double>>, grid, dim3(256), 0, s, static_cast<const Cplx<double>*>(A), lda,
-                         (int)na, upper ? 1 : 0, unit ? 1 : 0, static_cast<Cplx<double>*>(sc.buf));
+      hipLaunchKernelGGL((trtri_blocks<Cplx<double>, kSmallNB>), grid, dim3(256), 0, s, static_cast<const Cplx<double>*>(A), lda,
+                         (int)na, up, un, static_cast<Cplx<double>*>(sc.buf));
       break;
   }
   TR_TRY(hipGetLastError());
