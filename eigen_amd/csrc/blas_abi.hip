@@ -342,21 +342,31 @@ int gemm_host_impl(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k,
 
   const int es = kElemSize[dtype];
   const int64_t a_rows = stored_rows_is_m(opa) ? m : k, a_cols = stored_rows_is_m(opa) ? k : m;
-  const int64_t b_rows = stored_rows_is_m(opb) ? k : n, b_cols = stored_rows_is_m(opb) ? n : k;
+  // The device images are this library's own, so their m and n extents are rounded up to whole
+  // tiles and the kernel is launched on the rounded extents: every workgroup then runs the
+  // vector-load instantiation and no bounds-checked edge launch is needed.  What the padding
+  // holds does not matter: a row of op(A) beyond m only feeds rows of C beyond m, a column of
+  // op(B) beyond n only columns beyond n, and only the m x n window of C is copied back.  (k is
+  // not padded: the kernel zero-fills its last partial k-tile itself.)
+  int bm = 1, bn = 1, bk = 1;
+  eigamd_tile_shape(dtype, &bm, &bn, &bk);
+  const int64_t mp = round_up(m, bm), np = round_up(n, bn);
+  const int64_t a_rows_p = stored_rows_is_m(opa) ? mp : k, a_cols_p = stored_rows_is_m(opa) ? k : mp;
+  const int64_t b_rows_p = stored_rows_is_m(opb) ? k : np, b_cols_p = stored_rows_is_m(opb) ? np : k;
   // Device leading dimensions: 16-byte aligned rows so the vector kernels apply.
-  const int64_t dlda = round_up(std::max<int64_t>(a_rows, 1), 16);
-  const int64_t dldb = round_up(std::max<int64_t>(b_rows, 1), 16);
-  const int64_t dldc = round_up(m, 16);
+  const int64_t dlda = round_up(std::max<int64_t>(a_rows_p, 1), 16);
+  const int64_t dldb = round_up(std::max<int64_t>(b_rows_p, 1), 16);
+  const int64_t dldc = round_up(mp, 16);
   const bool beta_is_zero = beta[0] == 0.0 && beta[1] == 0.0;
 
   Staging& st = staging();
   std::lock_guard<std::mutex> lock(st.mu);
   if ((rc = st.init()) != EIGAMD_OK) return rc;
   if (k > 0) {
-    if ((rc = st.reserve(0, (size_t)dlda * a_cols * es)) != EIGAMD_OK) return rc;
-    if ((rc = st.reserve(1, (size_t)dldb * b_cols * es)) != EIGAMD_OK) return rc;
+    if ((rc = st.reserve(0, (size_t)dlda * a_cols_p * es)) != EIGAMD_OK) return rc;
+    if ((rc = st.reserve(1, (size_t)dldb * b_cols_p * es)) != EIGAMD_OK) return rc;
   }
-  if ((rc = st.reserve(2, (size_t)dldc * n * es)) != EIGAMD_OK) return rc;
+  if ((rc = st.reserve(2, (size_t)dldc * np * es)) != EIGAMD_OK) return rc;
 
   // Pipeline over column panels of C: while the kernel works on panel j, the host threads
   // stage panel j+1 (B and, unless beta == 0, C) and bring panel j-1 back.  A goes first.
@@ -393,7 +403,7 @@ int gemm_host_impl(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k,
     HIP_TRY(hipStreamWaitEvent(st.stream, st.uploaded, 0));
     GemmCall call;
     call.kind = dtype; call.opa = opa; call.opb = opb;
-    call.m = m; call.n = nb; call.k = k;
+    call.m = mp; call.n = round_up(nb, bn); call.k = k;   // whole tiles (the panel width is a multiple of every BN)
     call.alpha[0] = alpha[0]; call.alpha[1] = alpha[1];
     call.beta[0] = beta[0]; call.beta[1] = beta[1];
     call.A = st.buf[0]; call.lda = dlda;
@@ -420,6 +430,58 @@ int op_of(char ch) {  // blas/common.h:47-50
 }
 
 }  // namespace
+
+namespace eigamd {
+namespace {
+struct EdgeStreams {
+  std::mutex mu;
+  hipStream_t s[2] = {nullptr, nullptr};
+  hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
+  bool off = false;
+};
+EdgeStreams& edge_streams() {
+  static EdgeStreams e[kMaxDevices];
+  return e[current_device_slot()];
+}
+}  // namespace
+
+hipError_t edge_streams_fork(hipStream_t s, hipStream_t* a, hipStream_t* b) {
+  EdgeStreams& es = edge_streams();
+  std::lock_guard<std::mutex> lock(es.mu);
+  *a = *b = s;
+  if (es.off) return hipSuccess;
+  if (!es.s[0]) {
+    if (const char* e = getenv("EIGAMD_EDGE_STREAMS")) es.off = atoi(e) == 0;
+    if (es.off) return hipSuccess;
+    for (int i = 0; i < 2; ++i) {
+      hipError_t e = hipStreamCreateWithFlags(&es.s[i], hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&es.join[i], hipEventDisableTiming);
+      if (e != hipSuccess) return e;
+    }
+    hipError_t e = hipEventCreateWithFlags(&es.fork, hipEventDisableTiming);
+    if (e != hipSuccess) return e;
+  }
+  // An event's record is taken at enqueue time: calls from several host threads may share the
+  // events as long as each record / wait pair is issued under the lock.
+  hipError_t e = hipEventRecord(es.fork, s);
+  for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipStreamWaitEvent(es.s[i], es.fork, 0);
+  if (e != hipSuccess) return e;
+  *a = es.s[0];
+  *b = es.s[1];
+  return hipSuccess;
+}
+
+hipError_t edge_streams_join(hipStream_t s, hipStream_t a, hipStream_t b) {
+  if (a == s && b == s) return hipSuccess;
+  EdgeStreams& es = edge_streams();
+  std::lock_guard<std::mutex> lock(es.mu);
+  hipError_t e = hipEventRecord(es.join[0], a);
+  if (e == hipSuccess) e = hipStreamWaitEvent(s, es.join[0], 0);
+  if (e == hipSuccess) e = hipEventRecord(es.join[1], b);
+  if (e == hipSuccess) e = hipStreamWaitEvent(s, es.join[1], 0);
+  return e;
+}
+}  // namespace eigamd
 
 extern "C" {
 

@@ -721,6 +721,7 @@ template <typename T> hipError_t gemm_minus3(int64_t m, int64_t n, int64_t k, co
   c.kind = KindOf<T>::value;
   c.opa = OP_N; c.opb = OP_N;
   c.m = m; c.n = n; c.k = k;
+  c.serial_edges = true;   // the look-ahead owns the CU split between its streams
   c.alpha[0] = -1.0; c.alpha[1] = 0.0;
   c.beta[0] = 1.0; c.beta[1] = 0.0;
   c.A = A; c.lda = lda;
@@ -737,6 +738,7 @@ template <typename T> hipError_t gemm_assign(int64_t m, int64_t n, int64_t k, co
   c.kind = KindOf<T>::value;
   c.opa = OP_N; c.opb = OP_N;
   c.m = m; c.n = n; c.k = k;
+  c.serial_edges = true;
   c.alpha[0] = 1.0; c.alpha[1] = 0.0;
   c.beta[0] = 0.0; c.beta[1] = 0.0;
   c.A = A; c.lda = lda;
