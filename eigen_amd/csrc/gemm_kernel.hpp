@@ -448,7 +448,8 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
     const int krem = p.K - (t + LEAD) * BK;
     const bool do_store = (STEADY || t + 1 < t_end) && !(EIGAMD_ABLATE & 2);
     const bool do_load = (STEADY || t + LEAD < t_end) && !(EIGAMD_ABLATE & 1);
-    const bool guard = !STEADY && (GUARD || krem < BK);
+    // (a bounds-checked launch keeps its row / column checks in the steady loop; only the k check is dropped there)
+    const bool guard = STEADY ? GUARD : (GUARD || krem < BK);
     // In the interleaved pipeline the position of the copies among the MFMAs is the
     // point, so the instruction scheduler may not move anything across a used slot.
     auto slot = [&](int s) {
@@ -531,7 +532,7 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
   };
 
   int t = t_begin;
-  if constexpr (!GUARD) {
+  {
     const int nfull = min(p.K / BK, t_end);
     for (; t + LEAD < nfull; ++t) tile(t, std::true_type{});
   }
