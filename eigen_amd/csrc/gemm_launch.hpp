@@ -120,6 +120,11 @@ static hipError_t launch_layout(const GemmCall& c, hipStream_t stream) {
   hipError_t e;
   if (mi > 0 && ni > 0) {
     const bool bottom = c.m > mi, right = c.n > ni;
+    // A few rounds of tiles only: one bounds-checked launch over everything (about 8 % slower per
+    // tile than the vector-load instantiation) beats an interior launch plus edge strips whose
+    // workgroups each add a whole reduction to the critical path (dgemm 4000^3: 3.0 -> 2.4 ms).
+    const int64_t tiles_all = ((c.m + G::BM - 1) / G::BM) * ((c.n + G::BN - 1) / G::BN);
+    if ((bottom || right) && tiles_all <= 4 * 256) return launch_region<KIND, AK, BKC, true>(c, 0, 0, c.m, c.n, stream);
     hipStream_t sa = stream, sb = stream;
     // The strips write parts of C disjoint from the interior's and from each other's, and read
     // A and B only: the three launches may run side by side.
