@@ -471,6 +471,56 @@ hipError_t edge_streams_fork(hipStream_t s, hipStream_t* a, hipStream_t* b) {
   return hipSuccess;
 }
 
+namespace {
+// Buffers for the partial products of split reductions, one per (device, stream) that asked for
+// one: work queued on a stream runs in order, so one buffer per stream is never used by two
+// products at a time.  A process that multiplies on more than kSlots streams of a device gets no
+// buffer for the later ones (their products run unsplit).
+struct SplitWorkspaces {
+  static constexpr int kSlots = 8;
+  std::mutex mu;
+  int used = 0;
+  int off = -1;  // -1: environment not read yet
+  hipStream_t stream[kSlots];
+  void* buf[kSlots];
+  size_t bytes[kSlots];
+};
+SplitWorkspaces& split_workspaces() {
+  static SplitWorkspaces w[kMaxDevices];
+  return w[current_device_slot()];
+}
+}  // namespace
+
+void* splitk_workspace(hipStream_t s, size_t bytes) {
+  SplitWorkspaces& w = split_workspaces();
+  std::lock_guard<std::mutex> lock(w.mu);
+  if (w.off < 0) {
+    const char* e = getenv("EIGAMD_SPLITK");
+    w.off = (e && atoi(e) == 0) ? 1 : 0;
+  }
+  if (w.off) return nullptr;
+  int i = 0;
+  while (i < w.used && w.stream[i] != s) ++i;
+  if (i == w.used) {
+    if (w.used == SplitWorkspaces::kSlots) return nullptr;
+    w.stream[i] = s; w.buf[i] = nullptr; w.bytes[i] = 0;
+    ++w.used;
+  }
+  if (w.bytes[i] < bytes) {
+    // hipFree waits for the device, so nothing queued earlier still reads the old buffer.
+    if (w.buf[i]) (void)hipFree(w.buf[i]);
+    w.buf[i] = nullptr; w.bytes[i] = 0;
+    const size_t want = std::max(bytes, (size_t)32 << 20);
+    if (hipMalloc(&w.buf[i], want) != hipSuccess) {
+      (void)hipGetLastError();
+      w.buf[i] = nullptr;
+      return nullptr;
+    }
+    w.bytes[i] = want;
+  }
+  return w.buf[i];
+}
+
 hipError_t edge_streams_join(hipStream_t s, hipStream_t a, hipStream_t b) {
   if (a == s && b == s) return hipSuccess;
   EdgeStreams& es = edge_streams();

@@ -51,6 +51,10 @@ struct GemmParams {
   int ktri;               // structural zeros of a triangular operand: terms of the reduction known to
                           // vanish are skipped by whole k-tiles.  0 none; op(A)(row, k) = 0 for 1: k > row,
                           // 2: k < row; op(B)(k, col) = 0 for 3: k > col, 4: k < col
+  int splits;             // > 1: the grid holds `splits` copies of the tile sequence; copy s reduces over
+  int k_chunk;            // k in [s * k_chunk, min(K, (s + 1) * k_chunk)) (k_chunk a multiple of the k-tile)
+  int64_t split_stride;   // and writes its product to C + s * split_stride (elements): partial sums that
+                          // splitk_reduce_kernel adds up.  tri and ktri must be 0 then.
 };
 
 // Tile geometry per scalar kind.  WM x WN wavefronts per workgroup, each owning
@@ -284,9 +288,14 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
   // the sequence in groups of tile rows so that co-resident blocks of one
   // XCD share A and B panels in that XCD's L2.
   int tile_m, tile_n;
+  int split = 0;
   {
     const int nblk = p.tiles_m * p.tiles_n;
-    const int bid = blockIdx.x;
+    int bid = blockIdx.x;
+    if (p.splits > 1) {
+      split = bid / nblk;
+      bid -= split * nblk;
+    }
     const int q = nblk >> 3, rem = nblk & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     const int seq = p.xcd_remap ? (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx : bid;
@@ -305,8 +314,11 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
   if (p.tri == 1 && p.tri_r0 + m0 + BM - 1 < p.tri_c0 + n0) return;
   if (p.tri == 2 && p.tri_r0 + m0 > p.tri_c0 + n0 + BN - 1) return;
 
-  const Elem* __restrict__ A = static_cast<const Elem*>(p.A);
-  const Elem* __restrict__ B = static_cast<const Elem*>(p.B);
+  // Extent of this workgroup's reduction and where it starts.
+  const int k_first = split * p.k_chunk;
+  const int K = p.splits > 1 ? min(p.k_chunk, p.K - k_first) : p.K;
+  const Elem* __restrict__ A = static_cast<const Elem*>(p.A) + (AK ? (int64_t)k_first : (int64_t)k_first * p.lda);
+  const Elem* __restrict__ B = static_cast<const Elem*>(p.B) + (BKC ? (int64_t)k_first : (int64_t)k_first * p.ldb);
 
   IOA ioa; ioa.init(tid);
   IOB iob; iob.init(tid);
@@ -340,7 +352,7 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
   // k-tiles [t_begin, t_end) of this workgroup: all of them, or fewer when an operand is
   // triangular (the skipped tiles hold zeros only; tiles that straddle the diagonal are read,
   // their zeros are in memory).
-  int t_begin = 0, t_end = (p.K + BK - 1) / BK;
+  int t_begin = 0, t_end = (K + BK - 1) / BK;
   if (p.ktri == 1) t_end = min(t_end, (p.tri_r0 + m0 + BM - 1) / BK + 1);
   if (p.ktri == 2) t_begin = (p.tri_r0 + m0) / BK;
   if (p.ktri == 3) t_end = min(t_end, (p.tri_c0 + n0 + BN - 1) / BK + 1);
@@ -384,7 +396,7 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
   };
   // Whole tile `t` into the staging registers (prologue only).
   auto load_tile = [&](int t) {
-    const int krem = p.K - t * BK;
+    const int krem = K - t * BK;
     const bool guard = GUARD || krem < BK;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) load_chunk(c, guard, krem);
@@ -415,7 +427,7 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
   };
   const int mrow = wm0 + xi;                       // + i * TM
   const int nrow = wn0 + acc_row<KIND>(0, kk);     // + j * TM + acc_row(r, 0)
-  Elem* __restrict__ cbase = static_cast<Elem*>(p.C) + (int64_t)(m0 + mrow) + (int64_t)(n0 + nrow) * p.ldc;
+  Elem* __restrict__ cbase = static_cast<Elem*>(p.C) + split * p.split_stride + (int64_t)(m0 + mrow) + (int64_t)(n0 + nrow) * p.ldc;
   // C is read one column group (the NT index) at a time into a ring of kEpiStages register
   // buffers.  Where a group is small (32 VGPRs: f64) the ring has three buffers and the loads
   // of group 0 are issued at the top of the LAST k-tile, whose operand staging registers are
@@ -445,7 +457,7 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
     const Elem* sa = smem + (t & 1) * (LDS_A + LDS_B) + fa0;
     const Elem* sb = smem + (t & 1) * (LDS_A + LDS_B) + LDS_A + fb0;
     Elem* next_stage = smem + ((t + 1) & 1) * (LDS_A + LDS_B);
-    const int krem = p.K - (t + LEAD) * BK;
+    const int krem = K - (t + LEAD) * BK;
     const bool do_store = (STEADY || t + 1 < t_end) && !(EIGAMD_ABLATE & 2);
     const bool do_load = (STEADY || t + LEAD < t_end) && !(EIGAMD_ABLATE & 1);
     // (a bounds-checked launch keeps its row / column checks in the steady loop; only the k check is dropped there)
@@ -533,7 +545,7 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
 
   int t = t_begin;
   {
-    const int nfull = min(p.K / BK, t_end);
+    const int nfull = min(K / BK, t_end);
     for (; t + LEAD < nfull; ++t) tile(t, std::true_type{});
   }
   for (; t < t_end; ++t) tile(t, std::false_type{});
@@ -595,6 +607,48 @@ __global__ void scale_kernel(void* Cv, int64_t ldc, int M, int N, double beta_re
         const Elem c = *dst;
         v.x = (Real)beta_re * c.x - (Real)beta_im * c.y;
         v.y = (Real)beta_re * c.y + (Real)beta_im * c.x;
+      }
+      *dst = v;
+    }
+  }
+}
+
+// C = alpha * (P_0 + P_1 + ... + P_{S-1}) + beta * C, the partial products of a reduction split
+// over S copies of the tile sequence (GemmParams::splits); P_s is the dense m x n matrix at
+// P + s * m * n.  The sum runs in the order of s whatever order the copies finished in, so a
+// product gives the same bits on every run.  beta == 0 never reads C.
+template <int KIND>
+__global__ void splitk_reduce_kernel(const void* Pv, int splits, void* Cv, int64_t ldc, int M, int N,
+                                     double alpha_re, double alpha_im, double beta_re, double beta_im) {
+  typedef typename Traits<KIND>::Elem Elem;
+  typedef typename Traits<KIND>::Real Real;
+  const Elem* P = static_cast<const Elem*>(Pv);
+  Elem* C = static_cast<Elem*>(Cv);
+  const int64_t total = (int64_t)M * N;
+  const bool use_c = beta_re != 0.0 || beta_im != 0.0;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = idx / M, m = idx - n * M;
+    Elem sum = P[idx];
+    for (int s = 1; s < splits; ++s) {
+      const Elem v = P[idx + s * total];
+      if constexpr (!Traits<KIND>::kCplx) sum += v;
+      else { sum.x += v.x; sum.y += v.y; }
+    }
+    Elem* dst = C + m + n * ldc;
+    if constexpr (!Traits<KIND>::kCplx) {
+      Real v = (Real)alpha_re * sum;
+      if (use_c) v = fma((Real)beta_re, *dst, v);
+      *dst = v;
+    } else {
+      const Real alr = (Real)alpha_re, ali = (Real)alpha_im;
+      Elem v;
+      v.x = alr * sum.x - ali * sum.y;
+      v.y = alr * sum.y + ali * sum.x;
+      if (use_c) {
+        const Elem c = *dst;
+        v.x += (Real)beta_re * c.x - (Real)beta_im * c.y;
+        v.y += (Real)beta_re * c.y + (Real)beta_im * c.x;
       }
       *dst = v;
     }

@@ -69,6 +69,12 @@ inline int current_device_slot() {
 hipError_t edge_streams_fork(hipStream_t s, hipStream_t* a, hipStream_t* b);
 hipError_t edge_streams_join(hipStream_t s, hipStream_t a, hipStream_t b);
 
+// Device memory for the partial products of a reduction split over several workgroups per tile
+// (launch_whole): at least `bytes`, owned by the library, private to stream `s` of the current
+// device.  nullptr: none to be had (switched off by EIGAMD_SPLITK=0, too many streams, out of
+// memory); the product then runs unsplit.  Defined in blas_abi.hip.
+void* splitk_workspace(hipStream_t s, size_t bytes);
+
 hipError_t launch_gemm_f32(const GemmCall&, hipStream_t);
 hipError_t launch_gemm_f64(const GemmCall&, hipStream_t);
 hipError_t launch_gemm_c32(const GemmCall&, hipStream_t);
@@ -76,7 +82,8 @@ hipError_t launch_gemm_c64(const GemmCall&, hipStream_t);
 
 template <int KIND, bool AK, bool BKC, bool GUARD>
 static hipError_t launch_region(const GemmCall& c, int64_t r0, int64_t c0, int64_t rows,
-                                int64_t cols, hipStream_t stream) {
+                                int64_t cols, hipStream_t stream, int splits = 0, int k_chunk = 0,
+                                void* partials = nullptr) {
   typedef Geometry<KIND> G;
   typedef typename Traits<KIND>::Elem Elem;
   if (rows <= 0 || cols <= 0) return hipSuccess;
@@ -102,10 +109,74 @@ static hipError_t launch_region(const GemmCall& c, int64_t r0, int64_t c0, int64
   p.xcd_remap = (c.tri || c.ktri) ? 0 : tuning().xcd_remap;
   p.tri = c.tri; p.tri_r0 = (int)r0; p.tri_c0 = (int)c0;
   p.ktri = c.ktri;
-  const int64_t nblk = (int64_t)p.tiles_m * p.tiles_n;
+  p.splits = splits; p.k_chunk = k_chunk; p.split_stride = rows * cols;
+  if (splits > 1) {  // plain partial products, dense, one after the other
+    p.C = partials; p.ldc = rows;
+    p.alpha[0] = 1.0; p.alpha[1] = 0.0; p.beta[0] = 0.0; p.beta[1] = 0.0;
+  }
+  const int64_t nblk = (int64_t)p.tiles_m * p.tiles_n * (splits > 1 ? splits : 1);
   if (nblk > 0x7fffffff) return hipErrorInvalidValue;
   hipLaunchKernelGGL((gemm_kernel<KIND, AK, BKC, GUARD>), dim3((unsigned)nblk), dim3(G::THREADS),
                      tuning().extra_lds, stream, p);
+  return hipGetLastError();
+}
+
+// What one workgroup's tile costs, in microseconds: t0 + tk * k (prologue, epilogue and launch
+// share; one k of the main loop).  Measured on device-resident square products of 512 and 1024
+// (f64 0.136 / 0.259 ms, f32 0.149 / 0.269 ms); the complex figures follow from their tiles'
+// multiply-add counts.
+template <int KIND> struct TileCost;
+template <> struct TileCost<F64> { static constexpr double t0 = 13.0, tk = 0.240; };
+template <> struct TileCost<F32> { static constexpr double t0 = 29.0, tk = 0.234; };
+template <> struct TileCost<C64> { static constexpr double t0 = 13.0, tk = 0.480; };
+template <> struct TileCost<C32> { static constexpr double t0 = 29.0, tk = 0.468; };
+
+// A product of few tiles leaves most of the 256 compute units idle while each busy one walks the
+// whole reduction (dgemm 1024^3: 32 tiles, 0.26 ms, 8 TFLOP/s).  Returns how many pieces to cut
+// the reduction into (1: leave it whole) and the piece length, from a model of both variants: rounds of
+// 256 workgroups times the tile cost, plus for the split form the pass that adds the partial
+// products up (about 2.5 TB/s over pieces + 2 matrices, and a launch).
+template <int KIND>
+static int choose_splits(const GemmCall& c, int* k_chunk) {
+  typedef Geometry<KIND> G;
+  typedef TileCost<KIND> TC;
+  constexpr int kCUs = 256, kMaxSplits = 16;
+  constexpr size_t kMaxBytes = (size_t)256 << 20;
+  *k_chunk = (int)c.k;
+  if (c.tri || c.ktri || c.serial_edges || c.k < 8 * G::BK) return 1;
+  const int64_t tiles = ((c.m + G::BM - 1) / G::BM) * ((c.n + G::BN - 1) / G::BN);
+  if (tiles >= 2 * kCUs) return 1;
+  auto rounds = [&](int64_t blocks) { return (double)((blocks + kCUs - 1) / kCUs); };
+  const double mn_bytes = (double)c.m * c.n * G::ES;
+  const double whole = rounds(tiles) * (TC::t0 + TC::tk * c.k);
+  double best = whole * 0.85;  // a split has to win clearly
+  int best_s = 1;
+  for (int s = 2; s <= kMaxSplits; ++s) {
+    const int64_t kc = ((c.k + s - 1) / s + G::BK - 1) / G::BK * G::BK;
+    if (kc < 4 * G::BK) break;
+    const int pieces = (int)((c.k + kc - 1) / kc);
+    if (pieces != s) continue;  // the same pieces as a smaller s gave
+    if (mn_bytes * s > (double)kMaxBytes) break;
+    const double cost = rounds(tiles * s) * (TC::t0 + TC::tk * kc) + 6.0 + mn_bytes * (s + 2) / 2.5e6;
+    if (cost < best) { best = cost; best_s = s; *k_chunk = (int)kc; }
+  }
+  return best_s;
+}
+
+// One launch over all of C, its reduction split where that pays.
+template <int KIND, bool AK, bool BKC, bool GUARD>
+static hipError_t launch_whole(const GemmCall& c, hipStream_t stream) {
+  typedef Geometry<KIND> G;
+  int k_chunk = 0;
+  const int splits = choose_splits<KIND>(c, &k_chunk);
+  void* partials = splits > 1 ? splitk_workspace(stream, (size_t)splits * c.m * c.n * G::ES) : nullptr;
+  if (!partials) return launch_region<KIND, AK, BKC, GUARD>(c, 0, 0, c.m, c.n, stream);
+  hipError_t e = launch_region<KIND, AK, BKC, GUARD>(c, 0, 0, c.m, c.n, stream, splits, k_chunk, partials);
+  if (e != hipSuccess) return e;
+  const int64_t total = c.m * c.n;
+  const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL((splitk_reduce_kernel<KIND>), dim3(blocks), dim3(256), 0, stream, partials, splits,
+                     c.C, c.ldc, (int)c.m, (int)c.n, c.alpha[0], c.alpha[1], c.beta[0], c.beta[1]);
   return hipGetLastError();
 }
 
@@ -124,7 +195,8 @@ static hipError_t launch_layout(const GemmCall& c, hipStream_t stream) {
     // tile than the vector-load instantiation) beats an interior launch plus edge strips whose
     // workgroups each add a whole reduction to the critical path (dgemm 4000^3: 3.0 -> 2.4 ms).
     const int64_t tiles_all = ((c.m + G::BM - 1) / G::BM) * ((c.n + G::BN - 1) / G::BN);
-    if ((bottom || right) && tiles_all <= 4 * 256) return launch_region<KIND, AK, BKC, true>(c, 0, 0, c.m, c.n, stream);
+    if ((bottom || right) && tiles_all <= 4 * 256) return launch_whole<KIND, AK, BKC, true>(c, stream);
+    if (!bottom && !right) return launch_whole<KIND, AK, BKC, false>(c, stream);
     hipStream_t sa = stream, sb = stream;
     // The strips write parts of C disjoint from the interior's and from each other's, and read
     // A and B only: the three launches may run side by side.
@@ -141,7 +213,7 @@ static hipError_t launch_layout(const GemmCall& c, hipStream_t stream) {
     if (e != hipSuccess) return e;
     return fork ? edge_streams_join(stream, sa, sb) : hipSuccess;
   }
-  return launch_region<KIND, AK, BKC, true>(c, 0, 0, c.m, c.n, stream);
+  return launch_whole<KIND, AK, BKC, true>(c, stream);
 }
 
 template <int KIND>
