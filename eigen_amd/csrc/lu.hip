@@ -210,6 +210,12 @@ __device__ __forceinline__ void put_value(unsigned long long* p, double v, unsig
 __device__ __forceinline__ void put_value(unsigned long long* p, float v, unsigned G) {
   put_word(p, __float_as_uint(v), G);
 }
+// 32-bit word i of a value, in the order put_value stores them.
+__device__ __forceinline__ unsigned value_word(double v, int i) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return i == 0 ? (unsigned)b : (unsigned)(b >> 32);
+}
+__device__ __forceinline__ unsigned value_word(float v, int) { return __float_as_uint(v); }
 // Reads one value; false while any of its words is not of generation G yet.
 __device__ __forceinline__ bool get_value(const unsigned long long* p, double& v, unsigned G) {
   const unsigned long long lo = coherent_load(p), hi = coherent_load(p + 1);
@@ -257,44 +263,96 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
                   unsigned gen0, int* __restrict__ error, int* __restrict__ first_zero, int* __restrict__ nswaps) {
   __shared__ T s_u[kMaxBase];
   __shared__ T s_top[kMaxBase];
+  __shared__ unsigned s_pub[kRowsPerBlock / 64][kMaxBase * Words<T>::N];  // per wavefront: the words of the row it is about to publish
   __shared__ int s_win_row, s_flags;   // the winner's row; 1: the pivot is exactly zero, 2: gave up waiting
+  constexpr int NW = Words<T>::N;
   const int nparts = gridDim.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = blockIdx.x * kRowsPerBlock + threadIdx.x;
   const bool valid = r < rows;
   T row[kMaxBase];
 #pragma unroll
   for (int c = 0; c < kMaxBase; ++c) row[c] = (valid && c < jbw) ? P[r + (int64_t)c * ld] : (T)0;
 
+#ifdef EIGAMD_LU_TIMING
+  // Profiling builds: where a pivot column's time goes, summed over the columns of this launch
+  // (workgroup 0, thread 0; 10 ns ticks).
+  unsigned long long tick[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+#define LU_TICK(i) { const unsigned long long now_ = wall_clock64(); tick[i] += now_ - tprev; tprev = now_; }
+#else
+#define LU_TICK(i)
+#endif
+  // The registers of a row are rotated by one place per pivot column, so that the pivot column is
+  // always row[0] (a register index must be a constant): during column jj, row[c] holds panel
+  // column (jj + c) % 16; the columns right of jj are row[1 .. 15 - jj], the finished ones behind them.
+  int jj_done = 0;  // rotations so far
+#pragma unroll 1
   for (int jj = 0; jj < size; ++jj) {
+#ifdef EIGAMD_LU_TIMING
+    tprev = wall_clock64();
+#endif
     const unsigned G = gen0 + (unsigned)jj;
     BaseSlot<T>* buf = slots + (size_t)(G & 1u) * nparts;
     BaseTop<T>* top = tops + (G & 1u);
     // candidate of this workgroup for column jj ("no row" when all its rows are above jj)
-    T cur = (T)0;
-#pragma unroll
-    for (int c = 0; c < kMaxBase; ++c) cur = c == jj ? row[c] : cur;
+    const T cur = row[0];
     const bool cand = valid && r >= jj;
     const Candidate<T> best = block_best_all<T>(cand ? (T)fabs(cur) : (T)-1, cand ? r : kNoRow);
     const bool have = best.row != kNoRow;
-    if (have ? (valid && r == best.row) : threadIdx.x == 0) {
-      BaseSlot<T>* mine = buf + blockIdx.x;
-      put_value(mine->val, best.val, G);
-      put_word(&mine->row, (unsigned)best.row, G);
-      if (have) {
+    LU_TICK(0)
+    // The wavefront that holds the candidate's row publishes the slot with one store per lane:
+    // the lane of that row leaves it in LDS (same wavefront: LDS serves its accesses in order, no
+    // barrier needed), lanes [0, 16 NW) store its words, the next NW + 1 lanes |a| and the row
+    // index.  A workgroup without a candidate publishes "no row" from its first wavefront.
+    {
+      const int win_local = have ? best.row - (int)blockIdx.x * kRowsPerBlock : 0;
+      if ((win_local >> 6) == wave) {
+        unsigned* pub = s_pub[wave];
+        if (have && lane == (win_local & 63)) {
 #pragma unroll
-        for (int c = 0; c < kMaxBase; ++c) put_value(&mine->data[c * Words<T>::N], row[c], G);
+          for (int c = 0; c < kMaxBase; ++c)
+#pragma unroll
+            for (int w = 0; w < NW; ++w) pub[((jj + c) & (kMaxBase - 1)) * NW + w] = value_word(row[c], w);
+        }
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long* mine = reinterpret_cast<unsigned long long*>(buf + blockIdx.x);
+        unsigned payload = 0;
+        int word = -1;  // index into the slot: val[NW], row, data[16 NW]
+        if (lane < kMaxBase * NW) {
+          if (have) {
+            payload = pub[lane];
+            word = NW + 1 + lane;
+          }
+        } else if (lane < kMaxBase * NW + NW) {
+          payload = value_word(best.val, lane - kMaxBase * NW);
+          word = lane - kMaxBase * NW;
+        } else if (lane == kMaxBase * NW + NW) {
+          payload = (unsigned)best.row;
+          word = NW;
+        }
+        if (word >= 0) put_word(mine + word, payload, G);
+        __builtin_amdgcn_wave_barrier();
       }
     }
-    if (valid && r == jj) {
+    // Panel row jj (thread jj of workgroup 0) goes out the same way.
+    if (blockIdx.x == 0 && wave == 0) {
+      unsigned* pub = s_pub[0];
+      if (lane == jj) {
 #pragma unroll
-      for (int c = 0; c < kMaxBase; ++c) put_value(&top->data[c * Words<T>::N], row[c], G);
+        for (int c = 0; c < kMaxBase; ++c)
+#pragma unroll
+          for (int w = 0; w < NW; ++w) pub[((jj + c) & (kMaxBase - 1)) * NW + w] = value_word(row[c], w);
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (lane < kMaxBase * NW) put_word(&top->data[lane], pub[lane], G);
+      __builtin_amdgcn_wave_barrier();
     }
     // Wavefront 0 alone talks to the exchange area: it polls every workgroup's candidate of
     // generation G (lane = slot), picks the winner with shuffles, then fetches the two rows that
     // matter -- panel row jj and, when they are exchanged, the winner's row -- and leaves them in
     // LDS.  No workgroup barrier sits inside a polling loop; the other wavefronts wait at one.
+    LU_TICK(1)
     if (threadIdx.x < 64) {
-      const int lane = threadIdx.x;
       T val = (T)-1;
       int prow = kNoRow;
       unsigned spins = 0;
@@ -320,6 +378,7 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
         if (__any(give_up ? 1 : 0)) { failed = true; break; }
         __builtin_amdgcn_s_sleep(1);
       }
+      LU_TICK(2)
       // the same winner in every lane, hence in every workgroup
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) {
@@ -356,12 +415,14 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
           __builtin_amdgcn_s_sleep(1);
         }
       }
+      LU_TICK(3)
       if (lane == 0) {
         s_win_row = prow;
         s_flags = (zero_w ? 1 : 0) | (failed ? 2 : 0);
       }
     }
     __syncthreads();
+    LU_TICK(4)
     if (s_flags & 2) {
       if (threadIdx.x == 0) coherent_store(error, 1);
       break;
@@ -375,29 +436,29 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
       if (zero) atomicCAS(first_zero, -1, col_global + jj);  // keep the FIRST zero pivot (PartialPivLU.h:391-396)
       else if (swap) atomicAdd(nswaps, 1);
     }
-    if (swap && valid) {
-      if (r == win.row) {
+    if (swap && valid && (r == win.row || r == jj)) {
+      const T* src = r == jj ? s_u : s_top;  // (never both: swap means win.row != jj)
 #pragma unroll
-        for (int c = 0; c < kMaxBase; ++c) row[c] = s_top[c];
-      } else if (r == jj) {
-#pragma unroll
-        for (int c = 0; c < kMaxBase; ++c) row[c] = s_u[c];
-      }
+      for (int c = 0; c < kMaxBase; ++c) row[c] = src[(jj + c) & (kMaxBase - 1)];
     }
     if (valid && r > jj) {
-      T pivot = (T)1;
+      T l = row[0];
+      if (!zero) l = l / s_u[jj];  // the reference divides (lu.col(k).tail /= pivot, :389)
+      row[0] = l;
 #pragma unroll
-      for (int c = 0; c < kMaxBase; ++c) pivot = c == jj ? s_u[c] : pivot;
-      T l = (T)0;
-#pragma unroll
-      for (int c = 0; c < kMaxBase; ++c) l = c == jj ? row[c] : l;
-      if (!zero) l = l / pivot;  // the reference divides (lu.col(k).tail /= pivot, :389)
-#pragma unroll
-      for (int c = 0; c < kMaxBase; ++c) {
-        if (c == jj) row[c] = l;
-        else if (c > jj) row[c] = row[c] - l * s_u[c];
+      for (int c = 1; c < kMaxBase; ++c) {
+        const T x = row[c] - l * s_u[(jj + c) & (kMaxBase - 1)];
+        row[c] = c < kMaxBase - jj ? x : row[c];
       }
     }
+    {
+      const T first = row[0];
+#pragma unroll
+      for (int c = 0; c + 1 < kMaxBase; ++c) row[c] = row[c + 1];
+      row[kMaxBase - 1] = first;
+      ++jj_done;
+    }
+    LU_TICK(5)
     // No barrier here: wavefront 0 rewrites s_u / s_top / s_win_row only after the barrier inside
     // the next column's block_best_all, which every wavefront reaches after this update; and the
     // wavefronts rewrite their block_best_all slots only after the barrier above, behind which
@@ -405,10 +466,20 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
   }
 
   if (valid) {
+    // after `size` rotations (or fewer, when the loop was left early) row[c] is column (done + c) % 16
+    const int done = jj_done;
 #pragma unroll
-    for (int c = 0; c < kMaxBase; ++c)
-      if (c < jbw) P[r + (int64_t)c * ld] = row[c];
+    for (int c = 0; c < kMaxBase; ++c) {
+      const int col = (done + c) & (kMaxBase - 1);
+      if (col < jbw) P[r + (int64_t)col * ld] = row[c];
+    }
   }
+#ifdef EIGAMD_LU_TIMING
+  if (blockIdx.x == 0 && threadIdx.x == 0 && (col_global & 1023) == 0)
+    printf("lu_base_fused parts %d cols %d: reduce %llu publish %llu poll %llu fetch %llu barrier %llu update %llu (x10 ns)\n",
+           nparts, size, tick[0], tick[1], tick[2], tick[3], tick[4], tick[5]);
+#endif
+#undef LU_TICK
 }
 
 // After a base case inside a wider panel: the transpositions [k0, k1) (k1 - k0 <= 16) on
