@@ -32,6 +32,9 @@ namespace {
 #ifndef EIGAMD_LU_ROWS_PER_BLOCK
 #define EIGAMD_LU_ROWS_PER_BLOCK 256
 #endif
+#ifndef EIGAMD_LU_POLL_DELAY
+#define EIGAMD_LU_POLL_DELAY 0  // in units of 64 clocks
+#endif
 constexpr int kRowsPerBlock = EIGAMD_LU_ROWS_PER_BLOCK;  // rows of the panel one workgroup owns
 constexpr int kMaxBase = 16;        // widest unblocked panel (UnBlockedBound, PartialPivLU.h:336)
 
@@ -47,7 +50,50 @@ template <typename T> struct Side {
 };
 
 template <typename T> __device__ __forceinline__ bool better(T v, int r, T ov, int orow) {
-  return v > ov || (v == ov && r < orow);
+  return (v > ov) | ((v == ov) & (r < orow));
+}
+
+// Data-parallel-primitive moves: what lane `ctrl` designates holds, or this lane's own value
+// where the control designates no lane (or the row mask leaves this lane's row out).
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp_take(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_take(float v) {
+  return __int_as_float(dpp_take<CTRL, ROW_MASK>(__float_as_int(v)));
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_take(double v) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)dpp_take<CTRL, ROW_MASK>((int)(unsigned)b);
+  const unsigned hi = (unsigned)dpp_take<CTRL, ROW_MASK>((int)(unsigned)((unsigned long long)b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// Best candidate of a wavefront, left in lane 63: shifts by 1, 2, 4, 8 inside the rows of 16
+// lanes (row_shr), then lane 15 of rows 0 and 2 into rows 1 and 3 (row_bcast15), then lane 31 into
+// rows 2 and 3 (row_bcast31).  Register moves, against a trip through the LDS crossbar per shuffle.
+template <typename T> __device__ __forceinline__ void wave_best_to_lane63(T& val, int& row) {
+#define EIGAMD_BEST_STEP(CTRL, MASK)                                   \
+  {                                                                    \
+    const T ov = dpp_take<CTRL, MASK>(val);                            \
+    const int orow = dpp_take<CTRL, MASK>(row);                        \
+    const bool take = better(ov, orow, val, row);                      \
+    val = take ? ov : val;                                             \
+    row = take ? orow : row;                                           \
+  }
+  EIGAMD_BEST_STEP(0x111, 0xf)  // row_shr:1
+  EIGAMD_BEST_STEP(0x112, 0xf)  // row_shr:2
+  EIGAMD_BEST_STEP(0x114, 0xf)  // row_shr:4
+  EIGAMD_BEST_STEP(0x118, 0xf)  // row_shr:8
+  EIGAMD_BEST_STEP(0x142, 0xa)  // row_bcast15 into rows 1, 3
+  EIGAMD_BEST_STEP(0x143, 0xc)  // row_bcast31 into rows 2, 3
+#undef EIGAMD_BEST_STEP
+}
+__device__ __forceinline__ int from_lane63(int v) { return __builtin_amdgcn_readlane(v, 63); }
+__device__ __forceinline__ float from_lane63(float v) { return __int_as_float(from_lane63(__float_as_int(v))); }
+__device__ __forceinline__ double from_lane63(double v) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)from_lane63((int)(unsigned)b);
+  const unsigned hi = (unsigned)from_lane63((int)(unsigned)((unsigned long long)b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
 // Largest |a| with the smallest row index among ties, over one workgroup.
@@ -233,14 +279,9 @@ __device__ __forceinline__ bool get_value(const unsigned long long* p, float& v,
 template <typename T> __device__ Candidate<T> block_best_all(T val, int row) {
   __shared__ T s_val[kRowsPerBlock / 64];
   __shared__ int s_row[kRowsPerBlock / 64];
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const T ov = __shfl_down(val, off, 64);
-    const int orow = __shfl_down(row, off, 64);
-    if (better(ov, orow, val, row)) { val = ov; row = orow; }
-  }
+  wave_best_to_lane63(val, row);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0) { s_val[wave] = val; s_row[wave] = row; }
+  if (lane == 63) { s_val[wave] = val; s_row[wave] = row; }
   __syncthreads();
   Candidate<T> c = {s_val[0], s_row[0]};
 #pragma unroll
@@ -278,6 +319,7 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
   // Profiling builds: where a pivot column's time goes, summed over the columns of this launch
   // (workgroup 0, thread 0; 10 ns ticks).
   unsigned long long tick[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+  unsigned poll_rounds = 0, fetch_rounds = 0;
 #define LU_TICK(i) { const unsigned long long now_ = wall_clock64(); tick[i] += now_ - tprev; tprev = now_; }
 #else
 #define LU_TICK(i)
@@ -357,10 +399,16 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
       int prow = kNoRow;
       unsigned spins = 0;
       bool failed = false;
+      // A store takes about 0.4 us to become visible to the other workgroups and a poll that finds
+      // nothing costs a whole round trip: the first poll waits a little rather than leave at once.
+      __builtin_amdgcn_s_sleep(EIGAMD_LU_POLL_DELAY);
       for (;;) {
         bool ready = true;
         val = (T)-1;
         prow = kNoRow;
+#ifdef EIGAMD_LU_TIMING
+        ++poll_rounds;
+#endif
         for (int i = lane; i < nparts; i += 64) {
           T v;
           const bool okv = get_value(buf[i].val, v, G);
@@ -380,12 +428,9 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
       }
       LU_TICK(2)
       // the same winner in every lane, hence in every workgroup
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const T ov = __shfl_xor(val, off, 64);
-        const int orow = __shfl_xor(prow, off, 64);
-        if (better(ov, orow, val, prow)) { val = ov; prow = orow; }
-      }
+      wave_best_to_lane63(val, prow);
+      val = from_lane63(val);
+      prow = from_lane63(prow);
       if (prow == kNoRow) {  // nothing comparable in the column (NaNs): no exchange, pivot = the diagonal entry
         prow = jj;
         val = (T)1;
@@ -398,6 +443,9 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
         for (;;) {
           bool ready = true;
           T v = (T)0;
+#ifdef EIGAMD_LU_TIMING
+          ++fetch_rounds;
+#endif
           if (lane < kMaxBase) ready = get_value(&src_top[lane * Words<T>::N], v, G);
           else if (lane < 2 * kMaxBase && swap_w) ready = get_value(&src_win[(lane - kMaxBase) * Words<T>::N], v, G);
           if (__all(ready ? 1 : 0)) {
@@ -476,8 +524,8 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
   }
 #ifdef EIGAMD_LU_TIMING
   if (blockIdx.x == 0 && threadIdx.x == 0 && (col_global & 1023) == 0)
-    printf("lu_base_fused parts %d cols %d: reduce %llu publish %llu poll %llu fetch %llu barrier %llu update %llu (x10 ns)\n",
-           nparts, size, tick[0], tick[1], tick[2], tick[3], tick[4], tick[5]);
+    printf("lu_base_fused parts %d cols %d: reduce %llu publish %llu poll %llu fetch %llu barrier %llu update %llu (x10 ns) poll rounds %u fetch rounds %u\n",
+           nparts, size, tick[0], tick[1], tick[2], tick[3], tick[4], tick[5], poll_rounds, fetch_rounds);
 #endif
 #undef LU_TICK
 }
