@@ -530,6 +530,116 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
 #undef LU_TICK
 }
 
+// The same base case for panels of at most kSingleRows rows, in ONE workgroup of 1024 threads
+// with kSingleRpt rows per thread: the pivot search and the exchange of the two rows go through
+// LDS and two workgroup barriers per column, no global memory and no other workgroup is involved
+// (a column costs about 1 us here against 3.5 us or more through the exchange area).  Same
+// arithmetic as lu_base_fused, operation for operation.
+constexpr int kSingleThreads = 1024, kSingleRpt = 2, kSingleRows = kSingleThreads * kSingleRpt;
+template <typename T>
+__global__ void __launch_bounds__(kSingleThreads)
+    lu_base_single(T* __restrict__ P, int64_t ld, int rows, int jbw, int size, int* __restrict__ transp, int row_offset,
+                   int col_global, int* __restrict__ first_zero, int* __restrict__ nswaps) {
+  __shared__ T s_u[kMaxBase];
+  __shared__ T s_top[kMaxBase];
+  __shared__ T s_val[kSingleThreads / 64];
+  __shared__ int s_row[kSingleThreads / 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // row[q][c]: row tid + q * 1024; the columns rotate by one place per pivot column, so that the
+  // pivot column is always c == 0 (see lu_base_fused)
+  T row[kSingleRpt][kMaxBase];
+#pragma unroll
+  for (int q = 0; q < kSingleRpt; ++q)
+#pragma unroll
+    for (int c = 0; c < kMaxBase; ++c) {
+      const int r = tid + q * kSingleThreads;
+      row[q][c] = (r < rows && c < jbw) ? P[r + (int64_t)c * ld] : (T)0;
+    }
+  int done = 0;
+#pragma unroll 1
+  for (int jj = 0; jj < size; ++jj) {
+    T val = (T)-1;
+    int prow = kNoRow;
+#pragma unroll
+    for (int q = 0; q < kSingleRpt; ++q) {
+      const int r = tid + q * kSingleThreads;
+      if (r < rows && r >= jj) {
+        const T v = (T)fabs(row[q][0]);
+        if (better(v, r, val, prow)) { val = v; prow = r; }
+      }
+    }
+    wave_best_to_lane63(val, prow);
+    if (lane == 63) { s_val[wave] = val; s_row[wave] = prow; }
+    __syncthreads();
+    val = s_val[0];
+    prow = s_row[0];
+#pragma unroll
+    for (int w = 1; w < kSingleThreads / 64; ++w)
+      if (better(s_val[w], s_row[w], val, prow)) { val = s_val[w]; prow = s_row[w]; }
+    if (prow == kNoRow) {  // nothing comparable in the column (NaNs): no exchange, pivot = the diagonal entry
+      prow = jj;
+      val = (T)1;
+    }
+    const bool zero = !(val != (T)0);  // exactly zero
+    const bool swap = !zero && prow != jj;
+    // the pivot row (what every row below is updated with) and, for an exchange, panel row jj
+#pragma unroll
+    for (int q = 0; q < kSingleRpt; ++q) {
+      const int r = tid + q * kSingleThreads;
+      if (r == jj) {
+#pragma unroll
+        for (int c = 0; c < kMaxBase; ++c) (swap ? s_top : s_u)[(jj + c) & (kMaxBase - 1)] = row[q][c];
+      } else if (swap && r == prow) {
+#pragma unroll
+        for (int c = 0; c < kMaxBase; ++c) s_u[(jj + c) & (kMaxBase - 1)] = row[q][c];
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      transp[jj] = row_offset + prow;
+      if (zero) atomicCAS(first_zero, -1, col_global + jj);  // keep the FIRST zero pivot (PartialPivLU.h:391-396)
+      else if (swap) atomicAdd(nswaps, 1);
+    }
+#pragma unroll
+    for (int q = 0; q < kSingleRpt; ++q) {
+      const int r = tid + q * kSingleThreads;
+      if (swap && (r == jj || r == prow)) {
+        const T* src = r == jj ? s_u : s_top;
+#pragma unroll
+        for (int c = 0; c < kMaxBase; ++c) row[q][c] = src[(jj + c) & (kMaxBase - 1)];
+      }
+      if (r < rows && r > jj) {
+        T l = row[q][0];
+        if (!zero) l = l / s_u[jj];  // the reference divides (lu.col(k).tail /= pivot, PartialPivLU.h:389)
+        row[q][0] = l;
+#pragma unroll
+        for (int c = 1; c < kMaxBase; ++c) {
+          const T x = row[q][c] - l * s_u[(jj + c) & (kMaxBase - 1)];
+          row[q][c] = c < kMaxBase - jj ? x : row[q][c];
+        }
+      }
+      const T first = row[q][0];
+#pragma unroll
+      for (int c = 0; c + 1 < kMaxBase; ++c) row[q][c] = row[q][c + 1];
+      row[q][kMaxBase - 1] = first;
+    }
+    ++done;
+    // s_val / s_row are rewritten before the next column's first barrier and were last read before
+    // this column's second one; s_u / s_top are rewritten after the next column's first barrier.
+  }
+#pragma unroll
+  for (int q = 0; q < kSingleRpt; ++q) {
+    const int r = tid + q * kSingleThreads;
+    if (r < rows) {
+#pragma unroll
+      for (int c = 0; c < kMaxBase; ++c) {
+        const int col = (done + c) & (kMaxBase - 1);
+        if (col < jbw) P[r + (int64_t)col * ld] = row[q][c];
+      }
+    }
+  }
+}
+
 // After a base case inside a wider panel: the transpositions [k0, k1) (k1 - k0 <= 16) on
 // the other columns of the panel -- `nleft` columns starting at A_left and `nright`
 // columns starting at A_right -- and, on the right-hand ones, the forward substitution
@@ -896,12 +1006,26 @@ template <typename T> struct Workspace {
 };
 constexpr int kOwnScratch = 2 * kMaxSub;
 
+// EIGAMD_LU_SINGLE=0 sends short panels through the multi-workgroup base case too (experiments).
+inline bool single_base_enabled() {
+  static const bool on = [] {
+    const char* e = std::getenv("EIGAMD_LU_SINGLE");
+    return !(e && std::atoi(e) == 0);
+  }();
+  return on;
+}
+
 // unblocked_lu (PartialPivLU.h:357-412) on the rows x jbw sub-panel at P.
 template <typename T>
 hipError_t unblocked(T* P, int64_t ld, int64_t rows, int jbw, int* transp, int row_offset, int col_offset,
                      const Workspace<T>& w, hipStream_t s) {
   const int size = (int)std::min<int64_t>(rows, jbw);
   int nparts = (int)((rows + kRowsPerBlock - 1) / kRowsPerBlock);
+  if (rows <= kSingleRows && single_base_enabled()) {
+    hipLaunchKernelGGL(lu_base_single<T>, dim3(1), dim3(kSingleThreads), 0, s, P, ld, (int)rows, jbw, size, transp,
+                       row_offset, col_offset, w.first_zero, w.nswaps);
+    return hipGetLastError();
+  }
   if (nparts <= w.fused_capacity) {
     const unsigned gen0 = *w.generation;
     *w.generation += (unsigned)size;

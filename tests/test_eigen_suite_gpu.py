@@ -14,7 +14,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NAMES = ["product_large", "product_mmtr", "product_trsolve", "product_syrk", "product_symm", "product_trmm",
+NAMES = ["product_large", "product_small", "product_mmtr", "product_trsolve", "product_syrk", "product_symm", "product_trmm",
          "product_selfadjoint", "lu"]
 
 
