@@ -931,6 +931,133 @@ __global__ void __launch_bounds__(256) lu_trtri(const T* __restrict__ L, int64_t
   }
 }
 
+// The same inverse by block recursion, for bs = 64, 128 or 256 (the usual panel width):
+//   inv([A 0; C B]) = [inv(A) 0; -inv(B) C inv(A), inv(B)].
+// lu_trtri_diag inverts the 32 x 32 triangles on the diagonal (and writes the zeros above them);
+// lu_trtri_merge, once per level h = 32, 64, 128, fills the h x h blocks below pairs of finished
+// h x h inverses.  A workgroup owns 32 rows of such a block: it forms T = inv(B)(rows, :) * C in
+// LDS (the rows of inv(B) end at the diagonal) and then -T * inv(A), so nothing is updated in
+// place and the workgroups of a level are independent.  Every level runs 4 workgroups at
+// bs = 256; the chain is 4 short launches against one launch whose first workgroup walks all
+// rows (0.29 ms at bs = 256).
+template <typename T>
+__global__ void __launch_bounds__(64) lu_trtri_diag(const T* __restrict__ L, int64_t ldl, int bs, T* __restrict__ X) {
+  __shared__ T s_d[kInvCols][kInvCols + 1];  // s_d[k][i] = L(i, k) of the diagonal block, i > k
+  const int first = blockIdx.x * kInvCols;
+  for (int idx = threadIdx.x; idx < kInvCols * kInvCols; idx += 64) {
+    const int kk = idx / kInvCols, ii = idx % kInvCols;
+    s_d[kk][ii] = ii > kk ? L[(first + ii) + (int64_t)(first + kk) * ldl] : (T)0;
+  }
+  __syncthreads();
+  if (threadIdx.x < kInvCols) {
+    const int c = threadIdx.x;
+    T* col = X + (int64_t)(first + c) * bs;
+    for (int i = 0; i < first; ++i) col[i] = (T)0;
+    T x[kInvCols];
+#pragma unroll
+    for (int ii = 0; ii < kInvCols; ++ii) {
+      T v = (T)0;
+#pragma unroll
+      for (int kk = 0; kk < kInvCols; ++kk)
+        if (kk < ii) v += s_d[kk][ii] * x[kk];
+      x[ii] = ii < c ? (T)0 : (ii == c ? (T)1 : -v);
+    }
+#pragma unroll
+    for (int ii = 0; ii < kInvCols; ++ii) col[first + ii] = x[ii];
+  }
+}
+
+constexpr int kMergeRows = 32, kMergeK = 16, kMergeMaxH = 128;
+template <typename T>
+__global__ void __launch_bounds__(256) lu_trtri_merge(const T* __restrict__ L, int64_t ldl, int bs, int h, T* __restrict__ X) {
+  __shared__ __attribute__((aligned(16))) T s_t[kMergeRows][kMergeMaxH + 2];   // T = inv(B)(rows, :) * C
+  __shared__ __attribute__((aligned(16))) T s_b[kMergeK][kMergeMaxH + 2];      // k-chunk of the right-hand factor
+  __shared__ T s_a[kMergeRows][kMergeK + 1];                                   // k-chunk of the rows of inv(B)
+  const int per_pair = h / kMergeRows;
+  const int pair = blockIdx.x / per_pair, ib = blockIdx.x % per_pair;
+  const int base = pair * 2 * h;           // first row / column of A; B starts at base + h
+  const int r0 = base + h + ib * kMergeRows;  // first row of this workgroup (in X and in L)
+  const int ti = threadIdx.x % 16, tj = threadIdx.x / 16;  // rows ti, ti + 16; columns 2 tj + 32 m + {0, 1}
+  const int nm = h / 32;                     // column groups per thread (1, 2 or 4)
+  T acc[2][8];
+
+  // phase 0: T(i, j) = sum_k inv(B)(r0 + i, base + h + k) * L(base + h + k, base + j), k < 32 (ib + 1)
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[q][e] = (T)0;
+  const int klimit = (ib + 1) * kMergeRows;
+  for (int k0 = 0; k0 < klimit; k0 += kMergeK) {
+    for (int idx = threadIdx.x; idx < kMergeK * h; idx += 256) {
+      const int kk = idx % kMergeK, j = idx / kMergeK;
+      s_b[kk][j] = L[(base + h + k0 + kk) + (int64_t)(base + j) * ldl];
+    }
+    for (int idx = threadIdx.x; idx < kMergeRows * kMergeK; idx += 256) {
+      const int i = idx % kMergeRows, kk = idx / kMergeRows;
+      s_a[i][kk] = X[(r0 + i) + (int64_t)(base + h + k0 + kk) * bs];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < kMergeK; ++kk) {
+      const T a0 = s_a[ti][kk], a1 = s_a[ti + 16][kk];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        if (m < nm) {
+          const T b0 = s_b[kk][2 * tj + 32 * m], b1 = s_b[kk][2 * tj + 32 * m + 1];
+          acc[0][2 * m] += a0 * b0; acc[0][2 * m + 1] += a0 * b1;
+          acc[1][2 * m] += a1 * b0; acc[1][2 * m + 1] += a1 * b1;
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    if (m < nm) {
+      s_t[ti][2 * tj + 32 * m] = acc[0][2 * m]; s_t[ti][2 * tj + 32 * m + 1] = acc[0][2 * m + 1];
+      s_t[ti + 16][2 * tj + 32 * m] = acc[1][2 * m]; s_t[ti + 16][2 * tj + 32 * m + 1] = acc[1][2 * m + 1];
+    }
+  }
+  __syncthreads();
+
+  // phase 1: X(r0 + i, base + j) = - sum_k T(i, k) * inv(A)(base + k, base + j)   (inv(A)(k, j) = 0 for k < j: stored zeros)
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[q][e] = (T)0;
+  for (int k0 = 0; k0 < h; k0 += kMergeK) {
+    for (int idx = threadIdx.x; idx < kMergeK * h; idx += 256) {
+      const int kk = idx % kMergeK, j = idx / kMergeK;
+      s_b[kk][j] = X[(base + k0 + kk) + (int64_t)(base + j) * bs];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < kMergeK; ++kk) {
+      const T a0 = s_t[ti][k0 + kk], a1 = s_t[ti + 16][k0 + kk];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        if (m < nm) {
+          const T b0 = s_b[kk][2 * tj + 32 * m], b1 = s_b[kk][2 * tj + 32 * m + 1];
+          acc[0][2 * m] += a0 * b0; acc[0][2 * m + 1] += a0 * b1;
+          acc[1][2 * m] += a1 * b0; acc[1][2 * m + 1] += a1 * b1;
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    if (m < nm) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int j = base + 2 * tj + 32 * m + e;
+        X[(r0 + ti) + (int64_t)j * bs] = -acc[0][2 * m + e];
+        X[(r0 + ti + 16) + (int64_t)j * bs] = -acc[1][2 * m + e];
+      }
+    }
+  }
+}
+
 template <typename T> struct KindOf;
 template <> struct KindOf<float> { static constexpr int value = F32; };
 template <> struct KindOf<double> { static constexpr int value = F64; };
@@ -1098,7 +1225,20 @@ hipError_t trsm_unit_lower(const T* L, T* B, int64_t ld, int64_t bs, int64_t nco
 // fits one tile row of the GEMM (bs <= BM): a workgroup reads only the columns of B that it
 // overwrites, and it reads all of them before its epilogue stores.
 template <typename T> constexpr int gemm_tile_rows() { return Geometry<KindOf<T>::value>::BM; }
+inline bool recursive_inverse_enabled() {
+  static const bool on = [] {
+    const char* e = std::getenv("EIGAMD_LU_TRTRI_RECURSIVE");
+    return !(e && std::atoi(e) == 0);
+  }();
+  return on;
+}
 template <typename T> hipError_t make_inverse(const T* L, int64_t ldl, int64_t bs, T* X, hipStream_t s) {
+  if ((bs == 64 || bs == 128 || bs == 256) && recursive_inverse_enabled()) {
+    hipLaunchKernelGGL(lu_trtri_diag<T>, dim3((unsigned)(bs / kInvCols)), dim3(64), 0, s, L, ldl, (int)bs, X);
+    for (int h = kInvCols; h < bs; h *= 2)
+      hipLaunchKernelGGL(lu_trtri_merge<T>, dim3((unsigned)(bs / 64)), dim3(256), 0, s, L, ldl, (int)bs, h, X);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(lu_trtri<T>, dim3((unsigned)((bs + kInvCols - 1) / kInvCols)), dim3(256), 0, s, L, ldl, (int)bs, X);
   return hipGetLastError();
 }
