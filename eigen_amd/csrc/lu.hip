@@ -754,8 +754,8 @@ __global__ void __launch_bounds__(256) lu_rank_update(const T* __restrict__ A, c
 // ---- many transpositions at once ----------------------------------------------------
 //
 // A run of transpositions i <-> transp[i], i in [k0, k1), k1 - k0 <= kPlanSpan, applied in
-// order is a permutation of at most 2 (k1 - k0) rows.  lu_swap_plan works it out once (one
-// wavefront follows the run) as a list of moves "row dst receives what row src held";
+// order is a permutation of at most 2 (k1 - k0) rows.  lu_swap_plan works it out once as a list
+// of moves "row dst receives what row src held" (in no particular order);
 // lu_apply_plan then moves whole row segments with independent loads, instead of one
 // dependent load-store pair per transposition and column.
 constexpr int kPlanSpan = 256;
@@ -766,57 +766,44 @@ struct SwapPlan {
   int src[2 * kPlanSpan];
 };
 
-__global__ void __launch_bounds__(64) lu_swap_plan(const int* __restrict__ transp, int k0, int k1, SwapPlan* __restrict__ plan) {
-  __shared__ int s_top[kPlanSpan];    // row whose original content now sits at row k0 + t
-  __shared__ int s_orow[kPlanSpan];   // rows outside [k0, k1) that took part
-  __shared__ int s_osrc[kPlanSpan];   // ... and whose original content they hold now
+__global__ void __launch_bounds__(kPlanSpan) lu_swap_plan(const int* __restrict__ transp, int k0, int k1, SwapPlan* __restrict__ plan) {
+  // Every row that takes part is followed through the run by a thread of its own: the rows
+  // [k0, k1) and each row outside them that some transposition names (once, by the first
+  // transposition that names it).  The walks are independent of each other, read the run from
+  // LDS and keep their row in a register: no barrier inside the run.
   __shared__ int s_p[kPlanSpan];
-  __shared__ int s_found;
-  const int lane = threadIdx.x;
+  __shared__ int s_count;
+  const int t = threadIdx.x;
   const int span = k1 - k0;
-  for (int t = lane; t < span; t += 64) {
-    s_top[t] = k0 + t;
-    s_p[t] = transp[k0 + t];
+  if (t < span) s_p[t] = transp[k0 + t];
+  if (t == 0) s_count = 0;
+  __syncthreads();
+  int start[2] = {-1, -1};
+  if (t < span) {
+    start[0] = k0 + t;
+    const int p = s_p[t];
+    if (p < k0 || p >= k1) {
+      bool first = true;
+      for (int j = 0; j < t; ++j) first = first && s_p[j] != p;
+      if (first) start[1] = p;
+    }
+  }
+  int at[2] = {start[0], start[1]};
+  for (int i = 0; i < span; ++i) {
+    const int a = k0 + i, b = s_p[i];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) at[q] = at[q] == a ? b : (at[q] == b ? a : at[q]);
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    if (start[q] >= 0 && at[q] != start[q]) {  // row at[q] receives what row start[q] held
+      const int n = atomicAdd(&s_count, 1);
+      plan->dst[n] = at[q];
+      plan->src[n] = start[q];
+    }
   }
   __syncthreads();
-  int nout = 0;
-  for (int i = 0; i < span; ++i) {
-    const int p = s_p[i];
-    if (p == k0 + i) continue;
-    if (p >= k0 && p < k1) {
-      if (lane == 0) {
-        const int t = s_top[i];
-        s_top[i] = s_top[p - k0];
-        s_top[p - k0] = t;
-      }
-    } else {
-      if (lane == 0) s_found = -1;
-      __syncthreads();
-      for (int j = lane; j < nout; j += 64)
-        if (s_orow[j] == p) s_found = j;
-      __syncthreads();
-      int idx = s_found;
-      if (idx < 0) {
-        idx = nout++;
-        if (lane == 0) { s_orow[idx] = p; s_osrc[idx] = p; }
-      }
-      if (lane == 0) {
-        const int t = s_top[i];
-        s_top[i] = s_osrc[idx];
-        s_osrc[idx] = t;
-      }
-    }
-    __syncthreads();
-  }
-  // compact the moves that change something; one lane keeps the order simple
-  if (lane == 0) {
-    int n = 0;
-    for (int t = 0; t < span; ++t)
-      if (s_top[t] != k0 + t) { plan->dst[n] = k0 + t; plan->src[n] = s_top[t]; ++n; }
-    for (int j = 0; j < nout; ++j)
-      if (s_osrc[j] != s_orow[j]) { plan->dst[n] = s_orow[j]; plan->src[n] = s_osrc[j]; ++n; }
-    plan->count = n;
-  }
+  if (t == 0) plan->count = s_count;
 }
 
 // Applies a plan to `ncols` columns starting at A; a workgroup owns kPlanCols columns and
@@ -1175,7 +1162,7 @@ hipError_t unblocked(T* P, int64_t ld, int64_t rows, int jbw, int* transp, int r
 }
 
 hipError_t make_plan(const int* transp, int k0, int k1, SwapPlan* plan, hipStream_t s) {
-  hipLaunchKernelGGL(lu_swap_plan, dim3(1), dim3(64), 0, s, transp, k0, k1, plan);
+  hipLaunchKernelGGL(lu_swap_plan, dim3(1), dim3(kPlanSpan), 0, s, transp, k0, k1, plan);
   return hipGetLastError();
 }
 template <typename T> hipError_t apply_plan(T* A, int64_t ld, int64_t ncols, const SwapPlan* plan, hipStream_t s) {
