@@ -1338,7 +1338,7 @@ struct LuStreams {
 // EIGAMD_LU_WIDE fixes the width (a multiple of 256 up to kMaxSub * 256; 256 = one panel per
 // step); EIGAMD_LU_WIDE_T4 / _T2 move the thresholds.
 struct WidthRule {
-  int64_t fixed = 0, t4 = 26624, t2 = 18432;
+  int64_t fixed = 0, t4 = 20480, t2 = 16640;
 };
 const WidthRule& width_rule() {
   static const WidthRule r = [] {

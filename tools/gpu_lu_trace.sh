@@ -20,6 +20,19 @@ for s, e, _ in rows:
     if e <= cur_end: continue
     busy += e - max(s, cur_end); cur_end = e
 print(f"second factorisation: kernels {len(rows)}  span {(t1-t0)/1e6:.1f} ms  union busy {busy/1e6:.1f} ms ({100*busy/(t1-t0):.0f}%)")
-q = "select grid_x/workgroup_x as b, count(*), avg(end-start)/1e3, min(end-start)/1e3 from kernels where name like '%lu_base_fused%' group by b order by b"
+cols = [d[1] for d in cur.execute("pragma table_info(kernels)")]
+qcol = next((c for c in ("queue_id", "queue", "stream_id") if c in cols), None)
+if qcol:
+    per = {}
+    for s, e, name, qid in cur.execute(f"select start, end, name, {qcol} from kernels where start >= ? order by start", (t0,)):
+        short = name.replace("(anonymous namespace)::", "").split("(")[0].split("::")[-1].split("<")[0]
+        if "gemm_kernel" in name: short = "gemm_kernel (>0.3 ms)" if e - s > 300000 else "gemm_kernel (small)"
+        d = per.setdefault(qid, {})
+        c = d.setdefault(short, [0, 0]); c[0] += 1; c[1] += e - s
+    for qid, d in sorted(per.items()):
+        tot = sum(v[1] for v in d.values())
+        parts = ", ".join(f"{k} {v[0]} x = {v[1]/1e6:.1f}" for k, v in sorted(d.items(), key=lambda kv: -kv[1][1]))
+        print(f"  queue {qid} kernel time {tot/1e6:.1f} ms: {parts}")
+q = "select grid_x/workgroup_x as b, count(*), avg(end-start)/1e3, min(end-start)/1e3 from kernels where name like '%lu_base_%' group by b order by b"
 for r in cur.execute(q).fetchall()[::16]: print("lu_base_fused workgroups %4d calls %4d avg %7.1f us min %7.1f us" % r)
 PY
