@@ -122,14 +122,14 @@ static hipError_t launch_region(const GemmCall& c, int64_t r0, int64_t c0, int64
 }
 
 // What one workgroup's tile costs, in microseconds: t0 + tk * k (prologue, epilogue and launch
-// share; one k of the main loop).  Measured on device-resident square products of 512 and 1024
-// (f64 0.136 / 0.259 ms, f32 0.149 / 0.269 ms); the complex figures follow from their tiles'
-// multiply-add counts.
+// share; one k of the main loop).  Measured on device-resident square products of 512 and 1024,
+// each a single round of tiles (f64 0.136 / 0.259 ms, f32 0.149 / 0.269 ms, c64 and c32 both
+// 0.255 / 0.494 ms).
 template <int KIND> struct TileCost;
 template <> struct TileCost<F64> { static constexpr double t0 = 13.0, tk = 0.240; };
 template <> struct TileCost<F32> { static constexpr double t0 = 29.0, tk = 0.234; };
-template <> struct TileCost<C64> { static constexpr double t0 = 13.0, tk = 0.480; };
-template <> struct TileCost<C32> { static constexpr double t0 = 29.0, tk = 0.468; };
+template <> struct TileCost<C64> { static constexpr double t0 = 16.0, tk = 0.467; };
+template <> struct TileCost<C32> { static constexpr double t0 = 16.0, tk = 0.467; };
 
 // A product of few tiles leaves most of the 256 compute units idle while each busy one walks the
 // whole reduction (dgemm 1024^3: 32 tiles, 0.26 ms, 8 TFLOP/s).  Returns how many pieces to cut
