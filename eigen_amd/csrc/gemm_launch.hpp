@@ -163,21 +163,97 @@ static int choose_splits(const GemmCall& c, int* k_chunk) {
   return best_s;
 }
 
-// One launch over all of C, its reduction split where that pays.
+// A product of a few rounds of tiles whose last round is mostly empty (dgemm 5120^3: 800 tiles,
+// 3.1 rounds, the time of 4) is cut in two along tile rows or tile columns: a first part of whole
+// rounds, and the rest, whose reduction is split so that its workgroups are short.  Returns false
+// when that does not pay.  `cut`: first row (by_rows) or column of the second part.
+struct TailPlan {
+  bool by_rows;
+  int64_t cut;
+  int splits, k_chunk;
+};
+template <int KIND>
+static bool choose_tail(const GemmCall& c, TailPlan* plan) {
+  typedef Geometry<KIND> G;
+  typedef TileCost<KIND> TC;
+  constexpr int kCUs = 256, kMaxSplits = 16, kMaxRounds = 12;
+  constexpr size_t kMaxBytes = (size_t)256 << 20;
+  if (c.tri || c.ktri || c.serial_edges || c.k < 8 * G::BK) return false;
+  const int64_t tm = (c.m + G::BM - 1) / G::BM, tn = (c.n + G::BN - 1) / G::BN;
+  const int64_t tiles = tm * tn;
+  const int64_t rounds = (tiles + kCUs - 1) / kCUs;
+  if (rounds < 2 || rounds > kMaxRounds || tiles % kCUs == 0) return false;
+  const double t_tile = TC::t0 + TC::tk * c.k;
+  const int64_t over = tiles - (rounds - 1) * kCUs;  // tiles of the last round
+  double best = 0.92 * rounds * t_tile;
+  bool found = false;
+  for (int by_rows = 0; by_rows < 2; ++by_rows) {
+    const int64_t across = by_rows ? tn : tm;            // tiles per tile row / tile column
+    const int64_t lines = (over + across - 1) / across;  // tile rows / columns that go to the second part
+    if (lines >= (by_rows ? tm : tn)) continue;
+    const int64_t tail_tiles = lines * across;
+    const int64_t cut = by_rows ? (tm - lines) * G::BM : (tn - lines) * G::BN;
+    const double tail_elems = by_rows ? (double)(c.m - cut) * c.n : (double)c.m * (c.n - cut);
+    for (int s = 1; s <= kMaxSplits; ++s) {
+      const int64_t kc = ((c.k + s - 1) / s + G::BK - 1) / G::BK * G::BK;
+      if (s > 1 && kc < 4 * G::BK) break;
+      if ((int)((c.k + kc - 1) / kc) != s) continue;
+      if (s > 1 && tail_elems * G::ES * s > (double)kMaxBytes) break;
+      const double tail_rounds = (double)((tail_tiles * s + kCUs - 1) / kCUs);
+      const double cost = (rounds - 1) * t_tile + tail_rounds * (TC::t0 + TC::tk * kc) + 4.0 +
+                          (s > 1 ? 6.0 + tail_elems * G::ES * (s + 2) / 2.5e6 : 0.0);
+      if (cost < best) {
+        best = cost; found = true;
+        plan->by_rows = by_rows != 0; plan->cut = cut; plan->splits = s; plan->k_chunk = (int)kc;
+      }
+    }
+  }
+  return found;
+}
+
+// alpha * (sum of the partial products) + beta * C over a region of C
+template <int KIND>
+static hipError_t reduce_partials(const GemmCall& c, int64_t r0, int64_t c0, int64_t rows, int64_t cols, int splits,
+                                  const void* partials, hipStream_t stream) {
+  typedef typename Traits<KIND>::Elem Elem;
+  const int64_t total = rows * cols;
+  const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL((splitk_reduce_kernel<KIND>), dim3(blocks), dim3(256), 0, stream, partials, splits,
+                     static_cast<Elem*>(c.C) + r0 + c0 * c.ldc, c.ldc, (int)rows, (int)cols, c.alpha[0], c.alpha[1],
+                     c.beta[0], c.beta[1]);
+  return hipGetLastError();
+}
+
+// One launch over all of C, its reduction split where that pays; or two, when the last round
+// of tiles would be mostly empty.
 template <int KIND, bool AK, bool BKC, bool GUARD>
 static hipError_t launch_whole(const GemmCall& c, hipStream_t stream) {
   typedef Geometry<KIND> G;
   int k_chunk = 0;
   const int splits = choose_splits<KIND>(c, &k_chunk);
-  void* partials = splits > 1 ? splitk_workspace(stream, (size_t)splits * c.m * c.n * G::ES) : nullptr;
-  if (!partials) return launch_region<KIND, AK, BKC, GUARD>(c, 0, 0, c.m, c.n, stream);
-  hipError_t e = launch_region<KIND, AK, BKC, GUARD>(c, 0, 0, c.m, c.n, stream, splits, k_chunk, partials);
-  if (e != hipSuccess) return e;
-  const int64_t total = c.m * c.n;
-  const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 8192);
-  hipLaunchKernelGGL((splitk_reduce_kernel<KIND>), dim3(blocks), dim3(256), 0, stream, partials, splits,
-                     c.C, c.ldc, (int)c.m, (int)c.n, c.alpha[0], c.alpha[1], c.beta[0], c.beta[1]);
-  return hipGetLastError();
+  if (splits > 1) {
+    if (void* partials = splitk_workspace(stream, (size_t)splits * c.m * c.n * G::ES)) {
+      hipError_t e = launch_region<KIND, AK, BKC, GUARD>(c, 0, 0, c.m, c.n, stream, splits, k_chunk, partials);
+      if (e != hipSuccess) return e;
+      return reduce_partials<KIND>(c, 0, 0, c.m, c.n, splits, partials, stream);
+    }
+    return launch_region<KIND, AK, BKC, GUARD>(c, 0, 0, c.m, c.n, stream);
+  }
+  TailPlan t;
+  if (choose_tail<KIND>(c, &t)) {
+    const int64_t r0 = t.by_rows ? t.cut : 0, c0 = t.by_rows ? 0 : t.cut;
+    const int64_t rows = c.m - r0, cols = c.n - c0;
+    void* partials = t.splits > 1 ? splitk_workspace(stream, (size_t)t.splits * rows * cols * G::ES) : nullptr;
+    if (t.splits == 1 || partials) {
+      hipError_t e = launch_region<KIND, AK, BKC, GUARD>(c, 0, 0, t.by_rows ? t.cut : c.m, t.by_rows ? c.n : t.cut, stream);
+      if (e != hipSuccess) return e;
+      if (t.splits == 1) return launch_region<KIND, AK, BKC, GUARD>(c, r0, c0, rows, cols, stream);
+      e = launch_region<KIND, AK, BKC, GUARD>(c, r0, c0, rows, cols, stream, t.splits, t.k_chunk, partials);
+      if (e != hipSuccess) return e;
+      return reduce_partials<KIND>(c, r0, c0, rows, cols, t.splits, partials, stream);
+    }
+  }
+  return launch_region<KIND, AK, BKC, GUARD>(c, 0, 0, c.m, c.n, stream);
 }
 
 template <int KIND, bool AK, bool BKC>

@@ -98,3 +98,47 @@ def test_products_on_several_streams_at_once():
     for i in range(4):
         for rep in range(10):
             assert np.array_equal(cs[i][rep].to_numpy(), alone[i]), (i, rep)
+
+
+# (kind, m, n, k): more than two rounds of tiles with a mostly empty last one -- the launcher
+# multiplies whole rounds of tiles first and splits the reduction of the remaining tile rows or
+# columns.  Too large for the scalar oracle: a sample of rows x columns of C is recomputed on the
+# host in double precision from the same operands (same tolerance, the Netlib test ratio).
+TAIL_SHAPES = [(1, 2560, 7168, 160), (1, 2688, 7000, 384), (0, 4352, 8192, 256), (3, 1408, 2944, 200),
+               (2, 1664, 5120, 192), (1, 7168, 2560, 160)]
+
+
+@pytest.mark.parametrize("kind,m,n,k", TAIL_SHAPES)
+@pytest.mark.parametrize("ops", ["NN", "TN", "NT"])
+def test_two_part_launch_sampled(kind, m, n, k, ops):
+    import torch
+    from eigen_amd.device import DeviceMatrix, gemm_dev
+    opa, opb = ops
+    ar, ac = (m, k) if opa == "N" else (k, m)
+    br, bc = (k, n) if opb == "N" else (n, k)
+    a = DeviceMatrix(ar, ac, kind).fill_uniform(5)
+    b = DeviceMatrix(br, bc, kind).fill_uniform(6)
+    c = DeviceMatrix(m, n, kind).fill_uniform(7)
+    ha, hb, hc = a.to_numpy(), b.to_numpy(), c.to_numpy()
+    alpha, beta = (0.7, 1.3) if kind < 2 else (0.7 - 0.9j, 1.3 - 1.1j)
+    gemm_dev(opa, opb, alpha, a, b, beta, c)
+    torch.cuda.synchronize()
+    got = c.to_numpy()
+    rng = np.random.default_rng(m + n + kind)
+    # every tile row / column boundary region is hit: the last rows and columns always, the rest at random
+    rows = np.unique(np.concatenate([[0, m - 1, m - 200, m - 300], rng.integers(0, m, 96)]))
+    cols = np.unique(np.concatenate([[0, n - 1, n - 100, n - 300], rng.integers(0, n, 96)]))
+    wide = np.complex128 if kind >= 2 else np.float64
+    a_rows = opmat(ha, opa)[rows, :].astype(wide)
+    b_cols = opmat(hb, opb)[:, cols].astype(wide)
+    c0 = hc[np.ix_(rows, cols)]
+    want = alpha * (a_rows @ b_cols) + beta * c0.astype(wide)
+    r = ratio(kind, got[np.ix_(rows, cols)], want, alpha, a_rows, b_cols, beta, c0)
+    assert r < RATIO_LIMIT, (kind, ops, m, n, k, r)
+    # nothing outside the product's own arithmetic: the unsampled part obeys the checksum (C v) = alpha A (B v) + beta C0 v
+    v = np.linspace(-1.0, 1.0, n)
+    lhs = got.astype(wide) @ v
+    rhs = alpha * (opmat(ha, opa).astype(wide) @ (opmat(hb, opb).astype(wide) @ v)) + beta * (hc.astype(wide) @ v)
+    scale = np.abs(opmat(ha, opa)).astype(np.float64) @ (np.abs(opmat(hb, opb)).astype(np.float64) @ np.abs(v)) + \
+        np.abs(hc).astype(np.float64) @ np.abs(v)
+    assert (np.abs(lhs - rhs) <= 64 * ol.EPS[kind] * np.maximum(scale, 1.0) * 4).all()
