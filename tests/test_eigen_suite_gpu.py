@@ -1,5 +1,6 @@
-"""The reference's OWN unit tests for the path -- test/product_large.cpp, product_trsolve.cpp, product_syrk.cpp, product_symm.cpp, product_trmm.cpp,
-product_selfadjoint.cpp and lu.cpp of the Eigen tree -- compiled where they lie by
+"""The reference's OWN unit tests for the path -- test/product_large.cpp, product_small.cpp, product_mmtr.cpp,
+product_trsolve.cpp, product_syrk.cpp, product_symm.cpp, product_trmm.cpp, product_selfadjoint.cpp and lu.cpp of the
+Eigen tree -- compiled where they lie by
 oracle/Makefile with -DEIGEN_USE_BLAS (the reference's EIGEN_TEST_EXTERNAL_BLAS configuration,
 test/CMakeLists.txt:20-25) and linked against the HIP library, so every dense product, triangular
 solve, rank update and blocked LU above Eigen's size threshold in them runs on the GPU.  Their
