@@ -710,7 +710,17 @@ __global__ void lu_laswp(T* __restrict__ A, int64_t ld, int ncols, const int* __
 // panel after one base case (PartialPivLU.h:494 at the inner level).  Two flops per 16 bytes
 // of C: a streaming kernel -- thread = one row of A in registers, a 64-column slab of B in
 // LDS -- in ONE launch, where the GEMM kernel needs an interior launch and edge strips.
-constexpr int kRankCols = 64;
+// Columns of C a workgroup owns and how many of them a thread loads together.  32 / 16 against
+// 64 / 8: LU 8192^2 58.2 -> 55.9 ms (the kernel waits on its loads of C; more of them in flight and
+// twice the workgroups).  32 / 32 changes the float result in the last place (the compiler
+// reassociates something) and with it a pivot of the parity test: not used.
+#ifndef EIGAMD_LU_RANK_GROUP
+#define EIGAMD_LU_RANK_GROUP 16
+#endif
+#ifndef EIGAMD_LU_RANK_COLS
+#define EIGAMD_LU_RANK_COLS 32
+#endif
+constexpr int kRankCols = EIGAMD_LU_RANK_COLS;
 template <typename T>
 __global__ void __launch_bounds__(256) lu_rank_update(const T* __restrict__ A, const T* __restrict__ B, T* __restrict__ C,
                                                       int64_t ld, int rows, int cols, int jb) {
@@ -729,19 +739,20 @@ __global__ void __launch_bounds__(256) lu_rank_update(const T* __restrict__ A, c
   for (int k = 0; k < kMaxBase; ++k) a[k] = k < jb ? A[r + (int64_t)k * ld] : (T)0;
   T* Cr = C + r + (int64_t)c0 * ld;
   int j0 = 0;
-  for (; j0 + 8 <= nc; j0 += 8) {   // whole groups of 8 columns: independent loads, no tests
-    T c[8];
+  constexpr int kGroup = EIGAMD_LU_RANK_GROUP;
+  for (; j0 + kGroup <= nc; j0 += kGroup) {   // whole groups of columns: independent loads, no tests
+    T c[kGroup];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) c[u] = Cr[(int64_t)(j0 + u) * ld];
+    for (int u = 0; u < kGroup; ++u) c[u] = Cr[(int64_t)(j0 + u) * ld];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < kGroup; ++u) {
       T acc = (T)0;
 #pragma unroll
       for (int k = 0; k < kMaxBase; ++k) acc += a[k] * s_b[k][j0 + u];
       c[u] -= acc;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) Cr[(int64_t)(j0 + u) * ld] = c[u];
+    for (int u = 0; u < kGroup; ++u) Cr[(int64_t)(j0 + u) * ld] = c[u];
   }
   for (; j0 < nc; ++j0) {
     T acc = (T)0;
