@@ -126,16 +126,20 @@ static hipError_t launch_region(const GemmCall& c, int64_t r0, int64_t c0, int64
 // each a single round of tiles (f64 0.136 / 0.259 ms, f32 0.149 / 0.269 ms, c64 and c32 both
 // 0.255 / 0.494 ms).
 template <int KIND> struct TileCost;
+// The pass that adds partial products up reads them soon after they were written (they are still
+// in the last-level cache): 4 TB/s.  With 2.5 TB/s and a 15 % margin the model left the 128-row
+// products of a ztrsm unsplit; split, the 4096^2 solve takes 6.7 ms against 7.6.
+constexpr double kReduceBytesPerUs = 4.0e6;
 template <> struct TileCost<F64> { static constexpr double t0 = 13.0, tk = 0.240; };
 template <> struct TileCost<F32> { static constexpr double t0 = 29.0, tk = 0.234; };
-template <> struct TileCost<C64> { static constexpr double t0 = 16.0, tk = 0.467; };
+template <> struct TileCost<C64> { static constexpr double t0 = 13.0, tk = 0.467; };
 template <> struct TileCost<C32> { static constexpr double t0 = 16.0, tk = 0.467; };
 
 // A product of few tiles leaves most of the 256 compute units idle while each busy one walks the
 // whole reduction (dgemm 1024^3: 32 tiles, 0.26 ms, 8 TFLOP/s).  Returns how many pieces to cut
 // the reduction into (1: leave it whole) and the piece length, from a model of both variants: rounds of
 // 256 workgroups times the tile cost, plus for the split form the pass that adds the partial
-// products up (about 2.5 TB/s over pieces + 2 matrices, and a launch).
+// products up (pieces + 2 matrices at kReduceBytesPerUs, and a launch).
 template <int KIND>
 static int choose_splits(const GemmCall& c, int* k_chunk) {
   typedef Geometry<KIND> G;
@@ -149,7 +153,7 @@ static int choose_splits(const GemmCall& c, int* k_chunk) {
   auto rounds = [&](int64_t blocks) { return (double)((blocks + kCUs - 1) / kCUs); };
   const double mn_bytes = (double)c.m * c.n * G::ES;
   const double whole = rounds(tiles) * (TC::t0 + TC::tk * c.k);
-  double best = whole * 0.85;  // a split has to win clearly
+  double best = whole * 0.9;  // a split has to win clearly
   int best_s = 1;
   for (int s = 2; s <= kMaxSplits; ++s) {
     const int64_t kc = ((c.k + s - 1) / s + G::BK - 1) / G::BK * G::BK;
@@ -157,7 +161,7 @@ static int choose_splits(const GemmCall& c, int* k_chunk) {
     const int pieces = (int)((c.k + kc - 1) / kc);
     if (pieces != s) continue;  // the same pieces as a smaller s gave
     if (mn_bytes * s > (double)kMaxBytes) break;
-    const double cost = rounds(tiles * s) * (TC::t0 + TC::tk * kc) + 6.0 + mn_bytes * (s + 2) / 2.5e6;
+    const double cost = rounds(tiles * s) * (TC::t0 + TC::tk * kc) + 6.0 + mn_bytes * (s + 2) / kReduceBytesPerUs;
     if (cost < best) { best = cost; best_s = s; *k_chunk = (int)kc; }
   }
   return best_s;
@@ -179,6 +183,8 @@ static bool choose_tail(const GemmCall& c, TailPlan* plan) {
   constexpr int kCUs = 256, kMaxSplits = 16, kMaxRounds = 12;
   constexpr size_t kMaxBytes = (size_t)256 << 20;
   if (c.tri || c.ktri || c.serial_edges || c.k < 8 * G::BK) return false;
+  static const bool off = [] { const char* e = std::getenv("EIGAMD_TAILSPLIT"); return e && std::atoi(e) == 0; }();
+  if (off) return false;  // (experiments)
   const int64_t tm = (c.m + G::BM - 1) / G::BM, tn = (c.n + G::BN - 1) / G::BN;
   const int64_t tiles = tm * tn;
   const int64_t rounds = (tiles + kCUs - 1) / kCUs;
@@ -201,7 +207,7 @@ static bool choose_tail(const GemmCall& c, TailPlan* plan) {
       if (s > 1 && tail_elems * G::ES * s > (double)kMaxBytes) break;
       const double tail_rounds = (double)((tail_tiles * s + kCUs - 1) / kCUs);
       const double cost = (rounds - 1) * t_tile + tail_rounds * (TC::t0 + TC::tk * kc) + 4.0 +
-                          (s > 1 ? 6.0 + tail_elems * G::ES * (s + 2) / 2.5e6 : 0.0);
+                          (s > 1 ? 6.0 + tail_elems * G::ES * (s + 2) / kReduceBytesPerUs : 0.0);
       if (cost < best) {
         best = cost; found = true;
         plan->by_rows = by_rows != 0; plan->cut = cut; plan->splits = s; plan->k_chunk = (int)kc;
