@@ -743,7 +743,12 @@ int eigamd_getrf_dev(int dtype, int64_t m, int64_t n, void* d_a, int64_t lda, in
   if (m > 0 && n > 0) {
     int rc = ensure_device();
     if (rc != EIGAMD_OK) return rc;
-    HIP_TRY(getrf_device(dtype, m, n, d_a, lda, d_transp, max_block_size, &fz, &nb, static_cast<hipStream_t>(stream)));
+    const hipError_t e = getrf_device(dtype, m, n, d_a, lda, d_transp, max_block_size, &fz, &nb, static_cast<hipStream_t>(stream));
+    if (e == kLuNotResident)
+      return fail(EIGAMD_ERR_DEVICE,
+                  "LU: the workgroups of a panel kernel were not resident together (device shared with other work); "
+                  "the matrix is partly overwritten: restore it and call again with EIGAMD_LU_FUSED=0");
+    if (e != hipSuccess) return hip_fail(e, "getrf_device");
   }
   if (first_zero_pivot) *first_zero_pivot = fz;
   if (nb_transpositions) *nb_transpositions = nb;
@@ -791,11 +796,19 @@ static int lu_host_impl(int dtype, int64_t m, int64_t n, void* a, int64_t lda, i
   if ((rc = st.init()) != EIGAMD_OK) return rc;
   if ((rc = st.reserve(2, (size_t)dld * n * es)) != EIGAMD_OK) return rc;
   if ((rc = st.reserve(0, (size_t)size * sizeof(int) + 64)) != EIGAMD_OK) return rc;
-  if ((rc = st.upload(st.buf[2], dld, a, lda, m, n, es)) != EIGAMD_OK) return rc;
-  HIP_TRY(hipEventRecord(st.uploaded, st.h2d));
-  HIP_TRY(hipStreamWaitEvent(st.stream, st.uploaded, 0));
-  HIP_TRY(getrf_device(dtype, m, n, st.buf[2], dld, static_cast<int*>(st.buf[0]), 256, first_zero_pivot,
-                       nb_transpositions, st.stream));
+  // The caller's matrix is still intact while the device works on its copy: when the one-launch
+  // base case cannot run (its workgroups were not all resident, the device being shared with
+  // other work), the copy is made afresh and factorised through the per-column kernels.
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if ((rc = st.upload(st.buf[2], dld, a, lda, m, n, es)) != EIGAMD_OK) return rc;
+    HIP_TRY(hipEventRecord(st.uploaded, st.h2d));
+    HIP_TRY(hipStreamWaitEvent(st.stream, st.uploaded, 0));
+    const hipError_t e = getrf_device(dtype, m, n, st.buf[2], dld, static_cast<int*>(st.buf[0]), 256, first_zero_pivot,
+                                      nb_transpositions, st.stream, /*allow_fused=*/attempt == 0);
+    if (e == kLuNotResident && attempt == 0) continue;
+    if (e != hipSuccess) return hip_fail(e, "getrf_device");
+    break;
+  }
   HIP_TRY(hipMemcpyAsync(transp, st.buf[0], (size_t)size * sizeof(int), hipMemcpyDeviceToHost, st.stream));
   HIP_TRY(hipStreamSynchronize(st.stream));   // getrf_device has synchronised already; this covers the copy
   if ((rc = st.download(a, lda, st.buf[2], dld, m, n, es)) != EIGAMD_OK) return rc;

@@ -147,7 +147,11 @@ __global__ void lu_pivot(T* __restrict__ P, int64_t ld, int jbw, int jj, const C
   }
   val = __shfl(val, 0, 64);
   row = __shfl(row, 0, 64);
-  const bool zero = !(val != (T)0);  // exactly zero (or no candidate)
+  if (row == 0x7fffffff) {  // nothing comparable in the column (NaNs): no exchange, pivot = the diagonal entry
+    row = jj;
+    val = (T)1;
+  }
+  const bool zero = !(val != (T)0);  // exactly zero
   if (lane == 0) {
     transp[0] = row_offset + row;
     if (zero) {
@@ -334,7 +338,7 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
     tprev = wall_clock64();
 #endif
     const unsigned G = gen0 + (unsigned)jj;
-    BaseSlot<T>* buf = slots + (size_t)(G & 1u) * nparts;
+    BaseSlot<T>* buf = slots + (size_t)(G & 1u) * kMaxFusedParts;
     BaseTop<T>* top = tops + (G & 1u);
     // candidate of this workgroup for column jj ("no row" when all its rows are above jj)
     const T cur = row[0];
@@ -1113,6 +1117,19 @@ int block_size_rule(int64_t size, int64_t max_block) {  // PartialPivLU.h:443-44
     if (e_ != hipSuccess) return e_;         \
   } while (0)
 
+// Which base case a panel may take, read from the environment at every factorisation (so that a
+// test can walk all three): EIGAMD_LU_SINGLE=0 keeps short panels off the one-workgroup kernel,
+// EIGAMD_LU_FUSED=0 keeps panels off the one-launch kernel (the chain of per-column kernels runs).
+struct BaseCaseRule {
+  bool single = true, fused = true;
+};
+inline BaseCaseRule read_base_case_rule() {
+  BaseCaseRule r;
+  if (const char* e = std::getenv("EIGAMD_LU_SINGLE")) r.single = std::atoi(e) != 0;
+  if (const char* e = std::getenv("EIGAMD_LU_FUSED")) r.fused = std::atoi(e) != 0;
+  return r;
+}
+
 template <typename T> struct Workspace {
   Candidate<T>* partials;
   Side<T>* side;
@@ -1123,6 +1140,8 @@ template <typename T> struct Workspace {
   unsigned* generation; // host-side running count of pivot columns handed to lu_base_fused
   int* error;
   int fused_capacity;   // workgroups of lu_base_fused that are certainly resident together
+  BaseCaseRule rule;
+  int64_t wide_fixed, wide_t4, wide_t2;  // outer-step width rule of the look-ahead (outer_block)
   // Scratch of lu_swap_plan / lu_apply_plan and inverses of unit lower triangles (kPlanSpan^2
   // each).  Sets [2 * kMaxSub): the look-ahead, alternating per outer step, one entry per
   // kPlanSpan-wide piece of the step's block; the last set: blocked() itself (one stream).
@@ -1131,27 +1150,18 @@ template <typename T> struct Workspace {
 };
 constexpr int kOwnScratch = 2 * kMaxSub;
 
-// EIGAMD_LU_SINGLE=0 sends short panels through the multi-workgroup base case too (experiments).
-inline bool single_base_enabled() {
-  static const bool on = [] {
-    const char* e = std::getenv("EIGAMD_LU_SINGLE");
-    return !(e && std::atoi(e) == 0);
-  }();
-  return on;
-}
-
 // unblocked_lu (PartialPivLU.h:357-412) on the rows x jbw sub-panel at P.
 template <typename T>
 hipError_t unblocked(T* P, int64_t ld, int64_t rows, int jbw, int* transp, int row_offset, int col_offset,
                      const Workspace<T>& w, hipStream_t s) {
   const int size = (int)std::min<int64_t>(rows, jbw);
   int nparts = (int)((rows + kRowsPerBlock - 1) / kRowsPerBlock);
-  if (rows <= kSingleRows && single_base_enabled()) {
+  if (rows <= kSingleRows && w.rule.single) {
     hipLaunchKernelGGL(lu_base_single<T>, dim3(1), dim3(kSingleThreads), 0, s, P, ld, (int)rows, jbw, size, transp,
                        row_offset, col_offset, w.first_zero, w.nswaps);
     return hipGetLastError();
   }
-  if (nparts <= w.fused_capacity) {
+  if (nparts <= w.fused_capacity && w.rule.fused) {
     const unsigned gen0 = *w.generation;
     *w.generation += (unsigned)size;
     hipLaunchKernelGGL(lu_base_fused<T>, dim3(nparts), dim3(kRowsPerBlock), 0, s, P, ld, (int)rows, jbw, size, transp,
@@ -1351,19 +1361,15 @@ struct LuStreams {
 struct WidthRule {
   int64_t fixed = 0, t4 = 20480, t2 = 16640;
 };
-const WidthRule& width_rule() {
-  static const WidthRule r = [] {
-    WidthRule v;
-    if (const char* e = getenv("EIGAMD_LU_WIDE")) v.fixed = atoll(e);
-    if (const char* e = getenv("EIGAMD_LU_WIDE_T4")) v.t4 = atoll(e);
-    if (const char* e = getenv("EIGAMD_LU_WIDE_T2")) v.t2 = atoll(e);
-    return v;
-  }();
-  return r;
+WidthRule read_width_rule() {  // (per factorisation: tests set the variables between calls)
+  WidthRule v;
+  if (const char* e = getenv("EIGAMD_LU_WIDE")) v.fixed = atoll(e);
+  if (const char* e = getenv("EIGAMD_LU_WIDE_T4")) v.t4 = atoll(e);
+  if (const char* e = getenv("EIGAMD_LU_WIDE_T2")) v.t2 = atoll(e);
+  return v;
 }
-int64_t outer_block(int64_t remaining, int64_t rule_block) {
+int64_t outer_block(const WidthRule& r, int64_t remaining, int64_t rule_block) {
   if (rule_block < kPlanSpan) return rule_block;  // small matrices: the reference's own block
-  const WidthRule& r = width_rule();
   int64_t w = r.fixed > 0 ? r.fixed : (remaining >= r.t4 ? 4 * kPlanSpan : (remaining >= r.t2 ? 2 * kPlanSpan : kPlanSpan));
   return std::max<int64_t>(kPlanSpan, std::min<int64_t>(w / kPlanSpan * kPlanSpan, (int64_t)kMaxSub * kPlanSpan));
 }
@@ -1374,6 +1380,7 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
   const int64_t size = std::min(rows, cols);
   if (size <= kMaxBase) return blocked<T>(A, ld, 0, 0, rows, cols, transp, max_block, w, upd);
   const int64_t rule_block = block_size_rule(size, max_block);
+  const WidthRule wr = {w.wide_fixed, w.wide_t4, w.wide_t2};
   hipStream_t pan = st.panel;
   hipStream_t caller = upd;
   if (st.update) {  // the updates run on the stream that leaves the panel's CUs alone
@@ -1384,7 +1391,7 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
   LU_TRY(hipEventRecord(st.ready, upd));  // everything queued before the call
   int step = 0;
   for (int64_t k = 0, bs = 0; k < size; k += bs, ++step) {
-    bs = std::min(size - k, outer_block(size - k, rule_block));
+    bs = std::min(size - k, outer_block(wr, size - k, rule_block));
     const int64_t trows = rows - k - bs, tsize = size - k - bs;
     // The step's block in pieces of at most kPlanSpan rows: one swap plan and one inverted
     // triangle per piece.  Per-step scratch alternates: the panel stream prepares step k+1
@@ -1426,7 +1433,7 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
     };
     T* A21 = A + (k + bs) + k * ld;
     // columns of the next step's block first
-    const int64_t nb = trows ? std::min<int64_t>(tsize, outer_block(tsize, rule_block)) : 0;
+    const int64_t nb = trows ? std::min<int64_t>(tsize, outer_block(wr, tsize, rule_block)) : 0;
     if (nb > 0) {
       T* A12 = A + k + (k + bs) * ld;
       LU_TRY(swap_rows(A + (k + bs) * ld, nb));
@@ -1521,20 +1528,22 @@ hipError_t make_streams(LuStreams& st, int base_workgroups, int per_cu, int* tot
 
 template <typename T>
 hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp, int64_t max_block,
-                          int* first_zero_pivot, int* nb_transpositions, hipStream_t s) {
+                          int* first_zero_pivot, int* nb_transpositions, hipStream_t s, bool allow_fused) {
   LuScratch& sc = scratch();
   std::lock_guard<std::mutex> lock(sc.mu);
   const size_t nparts = (size_t)((m + kRowsPerBlock - 1) / kRowsPerBlock) + 1;
   auto round64 = [](size_t b) { return (b + 63) / 64 * 64; };
-  const size_t off_side = 64;  // first_zero, nswaps, arrived, exited, error live in the first 64 bytes
+  // Layout of the scratch buffer.  Everything the fused base case exchanges through lies at
+  // offsets that do not depend on the matrix: a word of the exchange area only ever holds
+  // (payload, generation) pairs, so a stale one can never show the current generation.
+  const size_t off_side = 64;  // first_zero, nswaps, error live in the first 64 bytes
   const size_t off_tops = off_side + round64(sizeof(Side<T>));
-  const size_t off_plan = off_tops + round64(2 * sizeof(BaseTop<T>));
+  const size_t off_slots = (off_tops + round64(2 * sizeof(BaseTop<T>)) + 1023) / 1024 * 1024;
+  const size_t off_plan = off_slots + 2 * (size_t)kMaxFusedParts * sizeof(BaseSlot<T>);
   constexpr int kSets = 2 * kMaxSub + 1;
   const size_t off_linv = off_plan + kSets * round64(sizeof(SwapPlan));
   const size_t off_partials = off_linv + kSets * round64((size_t)kPlanSpan * kPlanSpan * sizeof(T));
-  const size_t off_slots = off_partials + round64(nparts * sizeof(Candidate<T>));
-  const size_t nslots = 2 * std::min<size_t>(nparts, kMaxFusedParts);
-  const size_t need = off_slots + round64(nslots * sizeof(BaseSlot<T>));
+  const size_t need = off_partials + round64(nparts * sizeof(Candidate<T>));
   if (need > sc.cap) {
     if (sc.buf) LU_TRY(hipFree(sc.buf));
     sc.buf = nullptr;
@@ -1543,8 +1552,8 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
     sc.cap = need + 4096;
     sc.kind = -1;
   }
-  // The exchange area of the fused base case is reused from launch to launch without being
-  // cleared (its words carry their generation).  Clear it when its layout changes and
+  // The exchange area is reused from launch to launch without being cleared.  Clear it when
+  // the element type (hence the meaning of a slot's words) changes, after a reallocation and
   // before the generation count could wrap.
   if (sc.kind != KindOf<T>::value || sc.generation > 0xF0000000u) {
     LU_TRY(hipMemsetAsync(sc.buf, 0, sc.cap, s));
@@ -1553,6 +1562,12 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   }
   char* p = static_cast<char*>(sc.buf);
   Workspace<T> w;
+  w.rule = read_base_case_rule();
+  if (!allow_fused) w.rule.fused = false;
+  {
+    const WidthRule wr = read_width_rule();
+    w.wide_fixed = wr.fixed; w.wide_t4 = wr.t4; w.wide_t2 = wr.t2;
+  }
   w.first_zero = reinterpret_cast<int*>(p);
   w.nswaps = w.first_zero + 1;
   w.error = reinterpret_cast<int*>(p) + 4;
@@ -1597,21 +1612,24 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   LU_TRY(hipStreamSynchronize(s));
   *first_zero_pivot = out[0];
   *nb_transpositions = out[1];
-  if (out[4] != 0) return hipErrorLaunchFailure;  // a workgroup of the fused base case gave up waiting
+  // A workgroup of the one-launch base case gave up waiting for the others (they were not all
+  // resident: the device is shared with other work).  The matrix is then partly factorised and
+  // partly garbage; callers that still hold the original run again with allow_fused = false.
+  if (out[4] != 0 || (allow_fused && getenv("EIGAMD_LU_INJECT_FUSED_FAILURE"))) return kLuNotResident;
   return hipSuccess;
 }
 
 }  // namespace
 
 hipError_t getrf_device(int kind, int64_t m, int64_t n, void* A, int64_t ld, int* d_transp, int64_t max_block,
-                        int* first_zero_pivot, int* nb_transpositions, hipStream_t s) {
+                        int* first_zero_pivot, int* nb_transpositions, hipStream_t s, bool allow_fused) {
   if (max_block < 8) max_block = 8;
   if (kind == F64)
     return getrf_device_t<double>(m, n, static_cast<double*>(A), ld, d_transp, max_block, first_zero_pivot,
-                                  nb_transpositions, s);
+                                  nb_transpositions, s, allow_fused);
   if (kind == F32)
     return getrf_device_t<float>(m, n, static_cast<float*>(A), ld, d_transp, max_block, first_zero_pivot,
-                                 nb_transpositions, s);
+                                 nb_transpositions, s, allow_fused);
   return hipErrorInvalidValue;
 }
 

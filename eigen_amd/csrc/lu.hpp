@@ -10,8 +10,15 @@ namespace eigamd {
 // as global row indices; *first_zero_pivot the index of the first exactly-zero pivot
 // or -1; *nb_transpositions the number of actual row swaps.  Synchronises `s`.
 // max_block is the maxBlockSize of blocked_lu (256 at top level, 16 for a panel).
+//
+// The one-launch base case of a panel needs all its workgroups on the chip together.  When the
+// device is shared with other work and they are not, its workgroups give up after a bounded
+// wait and the call returns kLuNotResident with the matrix partly overwritten: the caller
+// restores the matrix and calls again with allow_fused = false (per-column kernels, whose
+// only grid-wide synchronisation is the kernel boundary).
+constexpr hipError_t kLuNotResident = hipErrorNotReady;
 hipError_t getrf_device(int kind, int64_t m, int64_t n, void* A, int64_t ld, int* d_transp, int64_t max_block,
-                        int* first_zero_pivot, int* nb_transpositions, hipStream_t s);
+                        int* first_zero_pivot, int* nb_transpositions, hipStream_t s, bool allow_fused = true);
 
 // Row transpositions i <-> d_transp[i], i in [k0, k1), on ncols columns starting at A
 // (row indices are rows of A).

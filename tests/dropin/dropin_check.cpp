@@ -6,7 +6,9 @@
 // reaches a GEMM kernel), in the style of test/product.h and bench/bench_gemm.cpp:256-288.
 //
 //   dropin_check            -> correctness cases, prints PASS/FAIL lines
-//   dropin_check bench N    -> times c.noalias() += a*b at N^3 through operator* (host pointers)
+//   dropin_check bench N [double|float]
+//                           -> c.noalias() += a*b at N^3 through operator* (host pointers): sampled rows
+//                              of the result are checked against lazyProduct, then the rate is printed
 #include <Eigen/Core>
 #include <Eigen/LU>
 #ifdef USE_EIGAMD_SEAM
@@ -202,19 +204,51 @@ static void lu_case(int n) {
 
 template <typename M> __attribute__((noinline)) void gemm_step(const M& a, const M& b, M& c) { c.noalias() += a * b; }
 
+// bench/bench_gemm.cpp:243-246 set-up (A, B random, C ones), three accumulations, then: C must equal
+// 1 + 3 A B.  A few rows are recomputed by the coefficient-based product in double precision and
+// compared with a normwise tolerance of 8 k eps |a_row| |B| (the bound of north_star, k eps |A| |B|).
+template <typename S> static int bench_case(const char* tag, int n) {
+  typedef Matrix<S, Dynamic, Dynamic> Mat;
+  Mat a = Mat::Random(n, n), b = Mat::Random(n, n), c = Mat::Ones(n, n);
+  gemm_step(a, b, c);
+  double best = 1e300;
+  for (int t = 0; t < 2; ++t) {
+    auto t0 = std::chrono::steady_clock::now();
+    gemm_step(a, b, c);
+    best = std::min(best, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  }
+  const int rows[5] = {0, 1, n / 3, n / 2 + 1, n - 1};
+  const double eps = (double)NumTraits<S>::epsilon();
+  int bad = 0;
+  for (int r : rows) {
+    const RowVectorXd ar = a.row(r).template cast<double>();
+    RowVectorXd want(n);
+    double bnorm2 = 0;
+    for (int j0 = 0; j0 < n; j0 += 512) {  // B in double, 512 columns at a time
+      const int nc = std::min(512, n - j0);
+      const MatrixXd bj = b.middleCols(j0, nc).template cast<double>();
+      want.segment(j0, nc) = ar.lazyProduct(bj);
+      if (r == rows[0]) bnorm2 += bj.squaredNorm();
+    }
+    static double bnorm = 0;
+    if (r == rows[0]) bnorm = std::sqrt(bnorm2);
+    want = (3.0 * want).array() + 1.0;
+    const double err = (c.row(r).template cast<double>() - want).norm();
+    const double bound = 8.0 * 3.0 * n * eps * ar.norm() * bnorm / std::sqrt((double)n);
+    const bool ok = err <= bound;
+    std::printf("%s row %d: |got - want| = %.3e, bound %.3e\n", ok ? "PASS" : "MISMATCH", r, err, bound);
+    bad += !ok;
+  }
+  std::printf("%s operator* %s %d^3: %d sampled rows against lazyProduct\n", bad ? "MISMATCH" : "VERIFIED", tag, n, 5);
+  std::printf("operator* %s %d^3 host-to-host: %.4f s  %.2f TFLOP/s\n", tag, n, best, 2.0 * n * n * n / best / 1e12);
+  return bad ? 1 : 0;
+}
+
 int main(int argc, char** argv) {
   if (argc >= 3 && !std::strcmp(argv[1], "bench")) {
     const int n = std::atoi(argv[2]);
-    MatrixXd a = MatrixXd::Random(n, n), b = MatrixXd::Random(n, n), c = MatrixXd::Ones(n, n);
-    gemm_step(a, b, c);
-    double best = 1e300;
-    for (int t = 0; t < 2; ++t) {
-      auto t0 = std::chrono::steady_clock::now();
-      gemm_step(a, b, c);
-      best = std::min(best, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-    }
-    std::printf("operator* double %d^3 host-to-host: %.4f s  %.2f TFLOP/s\n", n, best, 2.0 * n * n * n / best / 1e12);
-    return 0;
+    if (argc >= 4 && !std::strcmp(argv[3], "float")) return bench_case<float>("float", n);
+    return bench_case<double>("double", n);
   }
   product_cases<float>("float", 2e-5);
   product_cases<double>("double", 1e-13);

@@ -1,0 +1,147 @@
+"""The LU code paths that only large or forced configurations reach, each against a checker:
+
+* the configured size (PartialPivLU 32768 x 32768 double): outer steps 512 / 1024 columns wide,
+  look-ahead on two streams -- properties every partial-pivoting LU has plus the reference's
+  own acceptance criterion (test/lu.cpp:168) on sampled rows of P*A - L*U;
+* the same wide outer steps forced at sizes the CPU oracle finishes in seconds
+  (EIGAMD_LU_WIDE), against oracle/lu_oracle.c (Eigen/src/LU/PartialPivLU.h:429-498);
+* the per-column kernel chain (EIGAMD_LU_FUSED=0, EIGAMD_LU_SINGLE=0), including a column of
+  NaNs, and the second attempt of the host entry after a failed one-launch base case.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import eigen_amd
+from eigen_amd import lu as ealu
+from lu_checks import check_against_oracle, check_structure, perm_of, residual
+from test_lu_oracle import oracle_lu
+
+pytestmark = pytest.mark.gpu
+
+
+class env:
+    """Environment variables the library reads at every factorisation."""
+
+    def __init__(self, **kw):
+        self.kw = {k: str(v) for k, v in kw.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        os.environ.update(self.kw)
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def sampled_lu_residual(n, a_dev, a0_dev, transp, nblocks=6, block=128, seed=0):
+    """max over sampled blocks of rows R of ||(P A)[R, :] - L[R, :] U||_F / ||(P A)[R, :]||_F."""
+    import torch
+    lu = a_dev.as_strided()
+    perm = torch.as_tensor(perm_of(transp, n), device="cuda")
+    u = torch.triu(lu)
+    rng = np.random.default_rng(seed)
+    starts = sorted({0, n - block, *[int(x) for x in rng.integers(0, n - block, nblocks)]})
+    worst = 0.0
+    cols = torch.arange(n, device="cuda")
+    for r0 in starts:
+        rows = torch.arange(r0, r0 + block, device="cuda")
+        lr = lu[rows]                                              # block x n
+        lr = torch.where(cols[None, :] < rows[:, None], lr, torch.zeros_like(lr))
+        lr[torch.arange(block, device="cuda"), rows] = 1.0
+        pa = a0_dev.as_strided()[perm[rows]]
+        worst = max(worst, float(torch.linalg.norm(pa - lr @ u) / torch.linalg.norm(pa)))
+    return worst
+
+
+def test_lu_configured_size_32768():
+    import torch
+    from eigen_amd.device import DeviceMatrix
+    n = 32768
+    a = DeviceMatrix(n, n, eigen_amd.F64).fill_uniform(77)
+    transp, nb, fz = ealu.getrf_dev(a)
+    assert fz == -1
+    t = transp.cpu().numpy()
+    assert (t >= np.arange(n)).all() and (t < n).all()
+    assert nb == int((t != np.arange(n)).sum())
+    lu = a.as_strided()
+    lmax = 0.0
+    for c0 in range(0, n, 4096):                                   # |l_ij| <= 1, in column chunks
+        lmax = max(lmax, float(torch.tril(lu[:, c0:c0 + 4096], -1 - c0).abs().max()))
+    assert lmax <= 1.0, lmax
+    a0 = DeviceMatrix(n, n, eigen_amd.F64).fill_uniform(77)
+    res = sampled_lu_residual(n, a, a0, t)
+    assert res <= 8 * np.finfo(np.float64).eps * n, res
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("wide,n", [(512, 2048), (1024, 2048), (768, 2304), (1024, 2560)])
+def test_forced_wide_outer_steps_vs_oracle(dt, wide, n):
+    a = eigen_amd.fill_uniform_host(dt, n, n, 400 + n + wide)
+    a1, a2 = a.copy(order="F"), a.copy(order="F")
+    t1, nb1, r1 = oracle_lu(a1)
+    with env(EIGAMD_LU_WIDE=wide):
+        t2, nb2, r2 = ealu.blocked_lu(a2)
+    assert r1 == r2 == -1
+    first_diff = check_against_oracle(a, a1, t1, a2, t2, exact_pivots=dt == np.float64)
+    if first_diff is None:
+        assert nb1 == nb2
+
+
+def test_wide_steps_equal_narrow_steps_on_device():
+    """The same matrix through outer steps of 256, 512 and 1024 columns: identical transpositions,
+    factors equal to rounding (a k = 1024 product sums what four k = 256 products sum)."""
+    from eigen_amd.device import DeviceMatrix
+    n = 6144
+    out = []
+    for wide in (256, 512, 1024):
+        a = DeviceMatrix(n, n, eigen_amd.F64).fill_uniform(91)
+        with env(EIGAMD_LU_WIDE=wide):
+            transp, nb, fz = ealu.getrf_dev(a)
+        out.append((transp.cpu().numpy(), a.to_numpy(), nb, fz))
+    for t, lu, nb, fz in out[1:]:
+        assert np.array_equal(t, out[0][0]) and nb == out[0][2] and fz == out[0][3] == -1
+        assert np.abs(lu - out[0][1]).max() <= 64 * np.finfo(np.float64).eps * n * np.abs(out[0][1]).max()
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_per_column_kernel_chain_vs_oracle(dt):
+    for (m, n) in [(300, 300), (1500, 1100), (700, 40)]:
+        a = eigen_amd.fill_uniform_host(dt, m, n, 9 + m)
+        a1, a2 = a.copy(order="F"), a.copy(order="F")
+        t1, nb1, r1 = oracle_lu(a1)
+        with env(EIGAMD_LU_FUSED=0, EIGAMD_LU_SINGLE=0):
+            t2, nb2, r2 = ealu.blocked_lu(a2)
+        assert r1 == r2 == -1
+        check_against_oracle(a, a1, t1, a2, t2, exact_pivots=dt == np.float64)
+
+
+@pytest.mark.parametrize("knobs", [dict(EIGAMD_LU_FUSED=0, EIGAMD_LU_SINGLE=0), dict(EIGAMD_LU_SINGLE=0), dict()])
+def test_column_of_nans_takes_the_diagonal_entry(knobs):
+    """No comparable candidate in a column: every base case keeps the diagonal entry as the pivot,
+    exchanges nothing and stays inside the matrix (transposition = the column's own index)."""
+    n = 600
+    a = eigen_amd.fill_uniform_host(np.float64, n, n, 3)
+    a[:, 5] = np.nan
+    with env(**knobs):
+        t, nb, fz = ealu.blocked_lu(a)
+    assert t[5] == 5 and (t >= np.arange(n)).all() and (t < n).all()
+
+
+def test_host_entry_runs_again_without_the_fused_base_case():
+    """A failed one-launch base case (its workgroups not resident together) leaves the device copy
+    partly overwritten; the host entries still hold the caller's matrix and factorise it again
+    through the per-column kernels.  The failure is injected after the first attempt."""
+    m, n = 1500, 1100
+    a = eigen_amd.fill_uniform_host(np.float64, m, n, 5 + m)
+    a1, a2 = a.copy(order="F"), a.copy(order="F")
+    t1, nb1, r1 = oracle_lu(a1)
+    with env(EIGAMD_LU_INJECT_FUSED_FAILURE=1, EIGAMD_LU_SINGLE=0):
+        t2, nb2, r2 = ealu.blocked_lu(a2)
+    check_against_oracle(a, a1, t1, a2, t2, exact_pivots=True)
+    assert nb1 == nb2 and r1 == r2 == -1

