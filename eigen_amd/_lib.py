@@ -44,6 +44,8 @@ lib.eigamd_gemm_host.restype = ctypes.c_int
 lib.eigamd_gemm_host.argtypes = [ctypes.c_int] * 3 + [_i64] * 3 + [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64]
 lib.eigamd_gemm_dev.restype = ctypes.c_int
 lib.eigamd_gemm_dev.argtypes = [ctypes.c_int] * 3 + [_i64] * 3 + [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp]
+lib.eigamd_gemm_dev_noalloc.restype = ctypes.c_int
+lib.eigamd_gemm_dev_noalloc.argtypes = lib.eigamd_gemm_dev.argtypes
 lib.eigamd_gemm_ex_host.restype = ctypes.c_int
 lib.eigamd_gemm_ex_host.argtypes = [ctypes.c_int] * 5 + [_i64] * 3 + [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64]
 lib.eigamd_gemm_mixed_dev.restype = ctypes.c_int

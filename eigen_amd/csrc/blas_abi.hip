@@ -700,6 +700,78 @@ int eigamd_gemm_dev(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k
   return EIGAMD_OK;
 }
 
+}  // extern "C"
+
+// ---- the entry point that allocates nothing ---------------------------------------------
+//
+// eigamd_gemm_dev may call hipMalloc on its way (the partial-product buffer of a split
+// reduction, the helper streams of the edge launches).  Callers that must not allocate get the
+// same product with the partial products in a fixed device array that is part of the library's
+// code object: every GPU the library runs on holds its own copy from load to exit.
+namespace {
+constexpr size_t kNoAllocScratchBytes = (size_t)128 << 20;
+constexpr size_t kNoAllocMaxCBytes = kNoAllocScratchBytes / 16;  // up to 16 pieces of the reduction (choose_splits) fit
+}
+static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
+namespace {
+// The array's name is a host-side stand-in, not a device address: the address on each device
+// is asked for once, with that device current, and only that pointer is ever handed to a kernel.
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[kMaxDevices] = {};
+int noalloc_scratch(void** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices) return fail(EIGAMD_ERR_DEVICE, "device ordinal beyond the library's table");
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return fail(EIGAMD_ERR_DEVICE, "hipGetSymbolAddress returned no address for the scratch array");
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return EIGAMD_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int eigamd_gemm_dev_noalloc(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k,
+                            const void* alpha, const void* d_a, int64_t lda, const void* d_b,
+                            int64_t ldb, const void* beta, void* d_c, int64_t ldc, void* stream) {
+  if (dtype < 0 || dtype > 3) return fail(EIGAMD_ERR_ARG, "dtype out of range");
+  const int info = check_args(opa, opb, m, n, k, lda, ldb, ldc);
+  if (info) return fail(EIGAMD_ERR_ARG, "invalid argument #" + std::to_string(info));
+  if (m > 0x7fffffff || n > 0x7fffffff || k > 0x7fffffff)
+    return fail(EIGAMD_ERR_ARG, "extent exceeds 2^31-1");
+  if ((uint64_t)m * (uint64_t)n * kElemSize[dtype] > kNoAllocMaxCBytes)
+    return fail(EIGAMD_ERR_ARG, "eigamd_gemm_dev_noalloc: m * n * sizeof(scalar) = " +
+                                    std::to_string((uint64_t)m * (uint64_t)n * kElemSize[dtype]) + " bytes exceeds the maximum of " +
+                                    std::to_string(kNoAllocMaxCBytes) + " (use eigamd_gemm_dev)");
+  if (m == 0 || n == 0) return EIGAMD_OK;
+  int rc = ensure_device();
+  if (rc != EIGAMD_OK) return rc;
+  GemmCall call;
+  call.kind = dtype; call.opa = opa; call.opb = opb;
+  call.m = m; call.n = n; call.k = k;
+  read_scalar(dtype, alpha, call.alpha);
+  read_scalar(dtype, beta, call.beta);
+  if (k == 0 && call.beta[0] == 1.0 && call.beta[1] == 0.0) return EIGAMD_OK;
+  call.A = d_a; call.lda = lda;
+  call.B = d_b; call.ldb = ldb;
+  call.C = d_c; call.ldc = ldc;
+  void* area = nullptr;
+  if ((rc = noalloc_scratch(&area)) != EIGAMD_OK) return rc;
+  // A product this small is at most a few rounds of tiles: one launch over everything (no edge
+  // launches, hence no helper streams), its reduction split where that pays, the pieces in `area`.
+  // Every piece is written in full before the pass that adds them up reads it, so nothing in
+  // the array has to start at zero; two calls whose work overlaps on one GPU would share it.
+  call.partials = area;
+  call.partials_bytes = kNoAllocScratchBytes;
+  HIP_TRY(launch(call, static_cast<hipStream_t>(stream)));
+  return EIGAMD_OK;
+}
+
 int eigamd_fill_uniform_dev(int dtype, void* d_x, int64_t rows, int64_t cols, int64_t ld,
                             uint64_t seed, void* stream) {
   if (dtype < 0 || dtype > 3 || rows < 0 || cols < 0 || ld < std::max<int64_t>(rows, 1))

@@ -24,6 +24,10 @@ struct GemmCall {
   bool serial_edges = false;  // keep the edge launches on the caller's stream (callers that partition the CUs by stream)
   int tri = 0;  // 1 / 2: write (and read) only the lower / upper triangle of C (row >= col / row <= col)
   int ktri = 0; // structural zeros of a triangular operand (GemmParams::ktri)
+  // Caller-provided memory for the partial products of a split reduction (launch_whole) in
+  // place of splitk_workspace(): the launch path then allocates nothing.
+  void* partials = nullptr;
+  size_t partials_bytes = 0;
 };
 
 // Block-to-tile mapping knobs; the defaults are what the shipped library uses, the
@@ -238,7 +242,8 @@ static hipError_t launch_whole(const GemmCall& c, hipStream_t stream) {
   int k_chunk = 0;
   const int splits = choose_splits<KIND>(c, &k_chunk);
   if (splits > 1) {
-    if (void* partials = splitk_workspace(stream, (size_t)splits * c.m * c.n * G::ES)) {
+    const size_t bytes = (size_t)splits * c.m * c.n * G::ES;
+    if (void* partials = c.partials ? (bytes <= c.partials_bytes ? c.partials : nullptr) : splitk_workspace(stream, bytes)) {
       hipError_t e = launch_region<KIND, AK, BKC, GUARD>(c, 0, 0, c.m, c.n, stream, splits, k_chunk, partials);
       if (e != hipSuccess) return e;
       return reduce_partials<KIND>(c, 0, 0, c.m, c.n, splits, partials, stream);
@@ -249,7 +254,10 @@ static hipError_t launch_whole(const GemmCall& c, hipStream_t stream) {
   if (choose_tail<KIND>(c, &t)) {
     const int64_t r0 = t.by_rows ? t.cut : 0, c0 = t.by_rows ? 0 : t.cut;
     const int64_t rows = c.m - r0, cols = c.n - c0;
-    void* partials = t.splits > 1 ? splitk_workspace(stream, (size_t)t.splits * rows * cols * G::ES) : nullptr;
+    const size_t bytes = (size_t)t.splits * rows * cols * G::ES;
+    void* partials = t.splits <= 1 ? nullptr
+                     : c.partials  ? (bytes <= c.partials_bytes ? c.partials : nullptr)
+                                   : splitk_workspace(stream, bytes);
     if (t.splits == 1 || partials) {
       hipError_t e = launch_region<KIND, AK, BKC, GUARD>(c, 0, 0, t.by_rows ? t.cut : c.m, t.by_rows ? c.n : t.cut, stream);
       if (e != hipSuccess) return e;
@@ -282,7 +290,7 @@ static hipError_t launch_layout(const GemmCall& c, hipStream_t stream) {
     hipStream_t sa = stream, sb = stream;
     // The strips write parts of C disjoint from the interior's and from each other's, and read
     // A and B only: the three launches may run side by side.
-    const bool fork = (bottom || right) && !c.serial_edges;
+    const bool fork = (bottom || right) && !c.serial_edges && !c.partials;  // (helper streams are created on first use)
     if (fork) {
       e = edge_streams_fork(stream, &sa, &sb);
       if (e != hipSuccess) return e;

@@ -71,9 +71,10 @@ class DeviceMatrix:
         return m
 
 
-def gemm_dev(opa, opb, alpha, a, b, beta, c, stream=None):
+def gemm_dev(opa, opb, alpha, a, b, beta, c, stream=None, noalloc=False):
     """c <- alpha * op(a) * op(b) + beta * c on DeviceMatrix operands, asynchronously on
-    ``stream`` (default: torch's current stream)."""
+    ``stream`` (default: torch's current stream).  ``noalloc``: through
+    ``eigamd_gemm_dev_noalloc`` (nothing is allocated; C of at most 8 MiB)."""
     if not (a.kind == b.kind == c.kind):
         raise ValueError("operands must share one scalar kind")
     oa, ob = _OPCODE[opa], _OPCODE[opb]
@@ -81,10 +82,11 @@ def gemm_dev(opa, opb, alpha, a, b, beta, c, stream=None):
     k = a.cols if oa in (_lib.OP_N, _lib.OP_CONJ) else a.rows
     dt = _NP_OF_KIND[c.kind]
     al, be = np.array([alpha], dtype=dt), np.array([beta], dtype=dt)
-    rc = lib.eigamd_gemm_dev(c.kind, oa, ob, m, n, k, ctypes.c_void_p(al.ctypes.data), ctypes.c_void_p(a.ptr), a.ld,
-                             ctypes.c_void_p(b.ptr), b.ld, ctypes.c_void_p(be.ctypes.data), ctypes.c_void_p(c.ptr),
-                             c.ld, _stream_ptr(stream))
-    _lib.check(rc, "eigamd_gemm_dev")
+    fn = lib.eigamd_gemm_dev_noalloc if noalloc else lib.eigamd_gemm_dev
+    rc = fn(c.kind, oa, ob, m, n, k, ctypes.c_void_p(al.ctypes.data), ctypes.c_void_p(a.ptr), a.ld,
+            ctypes.c_void_p(b.ptr), b.ld, ctypes.c_void_p(be.ctypes.data), ctypes.c_void_p(c.ptr),
+            c.ld, _stream_ptr(stream))
+    _lib.check(rc, "eigamd_gemm_dev_noalloc" if noalloc else "eigamd_gemm_dev")
     return c
 
 

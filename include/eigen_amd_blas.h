@@ -67,6 +67,21 @@ int eigamd_gemm_dev(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k
                     const void* alpha, const void* d_a, int64_t lda, const void* d_b,
                     int64_t ldb, const void* beta, void* d_c, int64_t ldc, void* stream);
 
+/* ---- the same product for callers that cannot allocate ---------------------------
+ * No counterpart in the reference.  eigamd_gemm_dev may call hipMalloc on its way (the
+ * partial-product buffer of a reduction split over several workgroups per tile, helper
+ * streams); code under HIP graph capture, tight serving loops and harnesses that forbid
+ * allocation call this variant instead: same arguments, same result bit for bit, and no
+ * hipMalloc / hipFree / stream or event creation on any call.  The partial products live in a
+ * fixed 128 MiB device array inside the library (one copy per GPU, held until the process
+ * ends).  Limit: m * n * sizeof(scalar) <= 8 MiB (the products whose reduction the library
+ * splits); a larger C is rejected with EIGAMD_ERR_ARG and eigamd_last_error() names the limit.
+ * Calls whose work overlaps on one GPU (two streams, two threads) share that array and race:
+ * issue them on one stream, or serialise them. */
+int eigamd_gemm_dev_noalloc(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k,
+                            const void* alpha, const void* d_a, int64_t lda, const void* d_b,
+                            int64_t ldb, const void* beta, void* d_c, int64_t ldc, void* stream);
+
 /* ---- the forms Eigen keeps off the F77 route ------------------------------------
  * general_matrix_matrix_product (Eigen/src/Core/products/GeneralMatrixMatrix.h:52-69) is
  * also instantiated with one real and one complex operand (gebp_traits<complex,real> /
