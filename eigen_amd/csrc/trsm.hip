@@ -5,14 +5,24 @@
 // Replaces triangular_solve_matrix (Eigen/src/Core/products/TriangularSolverMatrix.h:40-…)
 // behind EIGEN_BLAS_FUNC(trsm) (blas/level3_impl.h:78-178).  The reference walks small
 // panels with scalar substitution and updates the rest with its GEMM kernel
-// (TriangularSolverMatrix.h:166,183); here the diagonal blocks (128 x 128) are inverted by a
-// small kernel, a block solve is ONE in-place product with that inverse, and the blocks are
-// combined by recursive halving, whose updates are MFMA GEMMs with long reductions.  As in
-// the reference the solve comes first and alpha is applied afterwards (level3_impl.h:163-175).
+// (TriangularSolverMatrix.h:166,183); here the diagonal blocks (128 x 128 or 256 x 256) are
+// inverted by a small kernel, a block solve is ONE in-place product with that inverse, and the
+// blocks are combined by recursive halving, whose updates are MFMA GEMMs with long reductions.
+// As in the reference the solve comes first and alpha is applied afterwards (level3_impl.h:163-175).
+//
+// Multiplying by an explicit inverse is as accurate as substitution only while the inverse is
+// not much larger than the triangle's own entries: its error grows with max|inv(T)| * max|T|,
+// the reference's substitution stays at a few eps whatever the triangle (it is backward stable
+// row by row).  So every diagonal block is measured after its inversion (trtri_decide): where
+// that product exceeds kGrowthLimit (or is not finite) the block is solved by substitution on
+// the device (trsm_block_subst, the reference's recurrence in 32-row steps) and its "inverse"
+// is replaced by the identity, so that the launch sequence does not depend on the data and
+// nothing has to come back to the host.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <functional>
 #include <mutex>
 
@@ -49,6 +59,13 @@ template <typename R> __device__ __forceinline__ Cplx<R> operator*(Cplx<R> a, Cp
   return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
 }
 template <typename R> __device__ __forceinline__ Cplx<R> operator-(Cplx<R> a) { return {-a.x, -a.y}; }
+template <typename R> __device__ __forceinline__ Cplx<R> operator-(Cplx<R> a, Cplx<R> b) { return {a.x - b.x, a.y - b.y}; }
+template <typename R> __device__ __forceinline__ Cplx<R> conj_of(Cplx<R> a) { return {a.x, -a.y}; }
+__device__ __forceinline__ float conj_of(float a) { return a; }
+__device__ __forceinline__ double conj_of(double a) { return a; }
+template <typename R> __device__ __forceinline__ double mag(Cplx<R> a) { return fabs((double)a.x) + fabs((double)a.y); }
+__device__ __forceinline__ double mag(float a) { return fabs((double)a); }
+__device__ __forceinline__ double mag(double a) { return fabs(a); }
 // Smith's division, as std::complex does it.
 template <typename R> __device__ __forceinline__ Cplx<R> operator/(Cplx<R> a, Cplx<R> b) {
   if (fabs(b.x) >= fabs(b.y)) {
@@ -145,6 +162,122 @@ __global__ void __launch_bounds__(256) trtri_blocks(const T* __restrict__ A, int
   }
 }
 
+
+// max over a workgroup of 256 threads; NaN wins (a block with a NaN must not pass as small).
+__device__ __forceinline__ double block_max_nan(double v) {
+  __shared__ double s_m[4];
+  __syncthreads();
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_down(v, off, 64);
+    v = (o > v || o != o) ? o : v;
+  }
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = s_m[0];
+  for (int w = 1; w < 4; ++w) r = (s_m[w] > r || s_m[w] != s_m[w]) ? s_m[w] : r;
+  return r;
+}
+
+// After trtri_blocks: flags[b] = 1 when max|inv(T_b)| * max|T_b| exceeds `limit` or is not finite;
+// the inverse of such a block is replaced by the identity (the block is solved by substitution).
+// grid = number of blocks, 256 threads.
+template <typename T, int NB>
+__global__ void __launch_bounds__(256) trtri_decide(const T* __restrict__ A, int64_t lda, int na, int upper, int unit,
+                                                    T* __restrict__ X, double limit, int* __restrict__ flags) {
+  const int b0 = blockIdx.x * NB;
+  const int bs = min(NB, na - b0);
+  const T* Ab = A + b0 + (int64_t)b0 * lda;
+  T* Xb = X + (int64_t)blockIdx.x * NB * NB;
+  double mx = 0.0, ma = unit ? 1.0 : 0.0;
+  for (int idx = threadIdx.x; idx < NB * NB; idx += 256) {
+    const double v = mag(Xb[idx]);
+    mx = (v > mx || v != v) ? v : mx;
+    const int i = idx % NB, k = idx / NB;  // stored triangle of the block: i >= k of the lower form
+    if (i < bs && k < bs && (i > k || (i == k && !unit))) {
+      const double a = mag(upper ? Ab[k + (int64_t)i * lda] : Ab[i + (int64_t)k * lda]);
+      ma = (a > ma || a != a) ? a : ma;
+    }
+  }
+  mx = block_max_nan(mx);
+  ma = block_max_nan(ma);
+  const bool subst = !(mx * ma <= limit);
+  if (threadIdx.x == 0) flags[blockIdx.x] = subst ? 1 : 0;
+  if (subst)
+    for (int idx = threadIdx.x; idx < NB * NB; idx += 256) Xb[idx] = (idx % NB == idx / NB) ? One<T>::v() : zero_of<T>();
+}
+
+// One diagonal block by substitution, in place, for the blocks trtri_decide flagged (others: the
+// kernel returns at once).  Canonical form: M x = b with M lower triangular of extent pb, one thread
+// per right-hand side; the unknowns are taken 32 at a time (the 32 x 32 triangle from LDS, then
+// the rows below get the chunk's contribution with one read-modify-write each).  The forms of
+// ?trsm_ map onto it through the index arithmetic of m_at():
+//   right side  X op(A) = B  is  op(A)^T X^T = B^T  (a right-hand side is a row of B),
+//   an upper triangular M is a lower one with its indices reversed (`rev`).
+// inc_i: distance in B between consecutive unknowns of one right-hand side, inc_c: between
+// right-hand sides.
+constexpr int kSubChunk = 32;
+template <typename T>
+__global__ void __launch_bounds__(256) trsm_block_subst(const int* __restrict__ flag, const T* __restrict__ A, int64_t lda, int pb,
+                                                        int rev, int right, int trans, int conj, int unit, T* __restrict__ B,
+                                                        int64_t inc_i, int64_t inc_c, int nrhs) {
+  if (*flag == 0) return;
+  __shared__ T s_t[kSubChunk][kLargeNB + 1];  // s_t[kk][i - i0] = M(i, i0 + kk)
+  auto m_at = [&](int i, int k) -> T {        // canonical indices, i >= k
+    if (i == k && unit) return One<T>::v();
+    int r = rev ? pb - 1 - i : i, c = rev ? pb - 1 - k : k;
+    if (right) { const int t = r; r = c; c = t; }
+    if (trans) { const int t = r; r = c; c = t; }
+    const T v = A[r + (int64_t)c * lda];
+    return conj ? conj_of(v) : v;
+  };
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  const bool active = col < nrhs;
+  T* b = B + (int64_t)col * inc_c;
+  auto b_at = [&](int i) -> T& { return b[(int64_t)(rev ? pb - 1 - i : i) * inc_i]; };
+  for (int i0 = 0; i0 < pb; i0 += kSubChunk) {
+    const int w = min(kSubChunk, pb - i0);
+    for (int idx = threadIdx.x; idx < kSubChunk * (pb - i0); idx += 256) {
+      const int kk = idx % kSubChunk, ii = idx / kSubChunk;
+      s_t[kk][ii] = (kk < w && ii >= kk) ? m_at(i0 + ii, i0 + kk) : (kk == ii ? One<T>::v() : zero_of<T>());
+    }
+    __syncthreads();
+    if (active) {
+      T x[kSubChunk];
+#pragma unroll
+      for (int ii = 0; ii < kSubChunk; ++ii) x[ii] = ii < w ? b_at(i0 + ii) : zero_of<T>();
+#pragma unroll
+      for (int ii = 0; ii < kSubChunk; ++ii) {
+        T v = x[ii];
+#pragma unroll
+        for (int kk = 0; kk < kSubChunk; ++kk)
+          if (kk < ii) v = v - s_t[kk][ii] * x[kk];
+        x[ii] = ii < w ? v / s_t[ii][ii] : zero_of<T>();
+      }
+#pragma unroll
+      for (int ii = 0; ii < kSubChunk; ++ii)
+        if (ii < w) b_at(i0 + ii) = x[ii];
+      for (int i = i0 + kSubChunk; i < pb; ++i) {
+        T acc = zero_of<T>();
+#pragma unroll
+        for (int kk = 0; kk < kSubChunk; ++kk) acc = acc + s_t[kk][i - i0] * x[kk];
+        b_at(i) = b_at(i) - acc;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// max|inv(T)| * max|T| above which a diagonal block is solved by substitution.  The error of the
+// product with the inverse is about that many times a substitution's; 8 keeps it inside what the
+// parity tests allow for rounding (test ratio 16).  EIGAMD_TRSM_GROWTH_LIMIT overrides it (0: every
+// block by substitution; inf: none), read at every call.
+constexpr double kGrowthLimit = 8.0;
+inline double growth_limit() {
+  if (const char* e = std::getenv("EIGAMD_TRSM_GROWTH_LIMIT")) return std::atof(e);
+  return kGrowthLimit;
+}
+
 hipError_t gemm(int kind, int opa, int opb, int64_t m, int64_t n, int64_t k, double alpha, const void* A, int64_t lda,
                 const void* B, int64_t ldb, double beta, void* C, int64_t ldc, hipStream_t s) {
   if (m <= 0 || n <= 0) return hipSuccess;
@@ -201,7 +334,8 @@ hipError_t trsm_device(int kind, bool left, bool upper, int op, bool unit, int64
   // inverses of all diagonal blocks (scratch shared by all callers: a use waits for the last one)
   InvScratch& sc = inv_scratch();
   std::lock_guard<std::mutex> lock(sc.mu);
-  const size_t need = (size_t)nblk * kNB * kNB * es;
+  const size_t inv_bytes = (size_t)nblk * kNB * kNB * es;
+  const size_t need = inv_bytes + (size_t)nblk * sizeof(int);
   if (!sc.done) TR_TRY(hipEventCreateWithFlags(&sc.done, hipEventDisableTiming));
   if (need > sc.cap) {
     if (sc.buf) {
@@ -244,10 +378,60 @@ hipError_t trsm_device(int kind, bool left, bool upper, int op, bool unit, int64
       break;
   }
   TR_TRY(hipGetLastError());
+  int* flags = reinterpret_cast<int*>(static_cast<char*>(sc.buf) + inv_bytes);
+  const double limit = growth_limit();
+  switch (kind) {
+    case F32:
+      if (kNB == kLargeNB)
+        hipLaunchKernelGGL((trtri_decide<float, kLargeNB>), dim3((unsigned)nblk), dim3(256), 0, s, static_cast<const float*>(A), lda,
+                           (int)na, up, un, static_cast<float*>(sc.buf), limit, flags);
+      else
+        hipLaunchKernelGGL((trtri_decide<float, kSmallNB>), dim3((unsigned)nblk), dim3(256), 0, s, static_cast<const float*>(A), lda,
+                           (int)na, up, un, static_cast<float*>(sc.buf), limit, flags);
+      break;
+    case F64:
+      if (kNB == kLargeNB)
+        hipLaunchKernelGGL((trtri_decide<double, kLargeNB>), dim3((unsigned)nblk), dim3(256), 0, s, static_cast<const double*>(A), lda,
+                           (int)na, up, un, static_cast<double*>(sc.buf), limit, flags);
+      else
+        hipLaunchKernelGGL((trtri_decide<double, kSmallNB>), dim3((unsigned)nblk), dim3(256), 0, s, static_cast<const double*>(A), lda,
+                           (int)na, up, un, static_cast<double*>(sc.buf), limit, flags);
+      break;
+    case C32:
+      hipLaunchKernelGGL((trtri_decide<Cplx<float>, kSmallNB>), dim3((unsigned)nblk), dim3(256), 0, s, static_cast<const Cplx<float>*>(A),
+                         lda, (int)na, up, un, static_cast<Cplx<float>*>(sc.buf), limit, flags);
+      break;
+    default:
+      hipLaunchKernelGGL((trtri_decide<Cplx<double>, kSmallNB>), dim3((unsigned)nblk), dim3(256), 0, s,
+                         static_cast<const Cplx<double>*>(A), lda, (int)na, up, un, static_cast<Cplx<double>*>(sc.buf), limit, flags);
+      break;
+  }
+  TR_TRY(hipGetLastError());
   auto inv = [&](int64_t j) { return static_cast<const char*>(sc.buf) + (size_t)j * kNB * kNB * es; };
 
-  const bool notrans = op == OP_N;
+  const bool notrans = op == OP_N || op == OP_CONJ;
   const bool eff_lower = (!upper) == notrans;  // op(A) is lower triangular
+  // The substitution form of one diagonal block (a no-op unless trtri_decide flagged it).
+  const int s_trans = notrans ? 0 : 1, s_conj = (op == OP_C || op == OP_CONJ) ? 1 : 0, s_right = left ? 0 : 1;
+  const int s_rev = (left ? eff_lower : !eff_lower) ? 0 : 1;  // the canonical matrix (op(A), or op(A)^T on the right) is upper
+  auto subst = [&](int64_t j, int64_t p0, int64_t pb) -> hipError_t {
+    const int64_t nrhs = left ? n : m;
+    const dim3 grid((unsigned)((nrhs + 255) / 256));
+    const void* Ajj = a_at(p0, p0);
+    void* Bj = left ? b_at(p0, 0) : b_at(0, p0);
+    const int64_t inc_i = left ? 1 : ldb, inc_c = left ? ldb : 1;
+#define EIGAMD_SUBST(TYPE)                                                                                                      \
+    hipLaunchKernelGGL((trsm_block_subst<TYPE>), grid, dim3(256), 0, s, flags + j, static_cast<const TYPE*>(Ajj), lda, (int)pb,  \
+                       s_rev, s_right, s_trans, s_conj, un, static_cast<TYPE*>(Bj), inc_i, inc_c, (int)nrhs)
+    switch (kind) {
+      case F32: EIGAMD_SUBST(float); break;
+      case F64: EIGAMD_SUBST(double); break;
+      case C32: EIGAMD_SUBST(Cplx<float>); break;
+      default:  EIGAMD_SUBST(Cplx<double>); break;
+    }
+#undef EIGAMD_SUBST
+    return hipGetLastError();
+  };
   // Recursive halving over the diagonal blocks [j0, j1): solve the half that does not depend
   // on the other, update the other half with ONE product whose reduction length is the size
   // of the first half (so the large updates run at GEMM speed and B is re-read O(log) times),
@@ -260,6 +444,7 @@ hipError_t trsm_device(int kind, bool left, bool upper, int op, bool unit, int64
   rec.run = [&](int64_t j0, int64_t j1) -> hipError_t {
     if (j1 - j0 == 1) {
       const int64_t p0 = j0 * kNB, pb = std::min<int64_t>(kNB, ext - p0);
+      TR_TRY(subst(j0, p0, pb));
       if (left)  // B_j <- op(inv_j) * B_j, in place (one tile row)
         return gemm(kind, op, OP_N, pb, n, pb, 1.0, inv(j0), kNB, b_at(p0, 0), ldb, 0.0, b_at(p0, 0), ldb, s);
       // B_j <- B_j * op(inv_j), in place (one tile column)
