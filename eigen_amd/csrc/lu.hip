@@ -1060,6 +1060,83 @@ __global__ void __launch_bounds__(256) lu_trtri_merge(const T* __restrict__ L, i
   }
 }
 
+// ---- when the inverse of a unit lower triangle is not small ------------------------------
+//
+// Partial pivoting bounds |l_ij| by 1, not the entries of inv(L): they are 2 to 4 for the
+// triangles a random matrix produces, but can reach 2^(bs-2) (unit lower with -1 everywhere below
+// the diagonal), and a product with such an inverse loses what the reference's substitution
+// (PartialPivLU.h:492, triangular_solve_matrix) keeps.  lu_inverse_guard measures max|inv(L)| right
+// after the inversion; above `limit` (or not finite) it sets *flag and replaces the inverse by the
+// identity, and lu_subst_flagged -- launched in front of every product with that inverse, a no-op
+// while the flag is clear -- solves by substitution instead.  The launch sequence is the same
+// either way, so nothing has to come back to the host.
+constexpr double kInverseGrowthLimit = 16.0;
+template <typename T>
+__global__ void __launch_bounds__(256) lu_inverse_guard(T* __restrict__ X, int bs, double limit, int* __restrict__ flag) {
+  __shared__ double s_m[4];
+  double mx = 0.0;
+  for (int idx = threadIdx.x; idx < bs * bs; idx += 256) {
+    const double v = fabs((double)X[idx]);
+    mx = (v > mx || v != v) ? v : mx;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_down(mx, off, 64);
+    mx = (o > mx || o != o) ? o : mx;
+  }
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = s_m[0];
+  for (int w = 1; w < 4; ++w) mx = (s_m[w] > mx || s_m[w] != s_m[w]) ? s_m[w] : mx;
+  const bool subst = !(mx <= limit);
+  if (threadIdx.x == 0) *flag = subst ? 1 : 0;
+  if (subst)
+    for (int idx = threadIdx.x; idx < bs * bs; idx += 256) X[idx] = (idx % bs == idx / bs) ? (T)1 : (T)0;
+}
+
+// B (bs x ncols) <- L^-1 B by substitution, L unit lower (bs <= kPlanSpan), one thread per column,
+// the unknowns 32 at a time: their 32 x 32 triangle from LDS, then one read-modify-write per row below.
+template <typename T>
+__global__ void __launch_bounds__(256) lu_subst_flagged(const int* __restrict__ flag, const T* __restrict__ L, int64_t ldl, int bs,
+                                                        T* __restrict__ B, int64_t ldb, int ncols) {
+  if (*flag == 0) return;
+  constexpr int CH = 32;
+  __shared__ T s_t[CH][kPlanSpan + 1];  // s_t[kk][i - i0] = L(i, i0 + kk), i > i0 + kk
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  T* b = B + (int64_t)col * ldb;
+  for (int i0 = 0; i0 < bs; i0 += CH) {
+    const int w = min(CH, bs - i0);
+    for (int idx = threadIdx.x; idx < CH * (bs - i0); idx += 256) {
+      const int kk = idx % CH, ii = idx / CH;
+      s_t[kk][ii] = (kk < w && ii > kk) ? L[(i0 + ii) + (int64_t)(i0 + kk) * ldl] : (T)0;
+    }
+    __syncthreads();
+    if (col < ncols) {
+      T x[CH];
+#pragma unroll
+      for (int ii = 0; ii < CH; ++ii) x[ii] = ii < w ? b[i0 + ii] : (T)0;
+#pragma unroll
+      for (int ii = 0; ii < CH; ++ii) {
+        T v = x[ii];
+#pragma unroll
+        for (int kk = 0; kk < CH; ++kk)
+          if (kk < ii) v -= s_t[kk][ii] * x[kk];
+        x[ii] = v;
+      }
+#pragma unroll
+      for (int ii = 0; ii < CH; ++ii)
+        if (ii < w) b[i0 + ii] = x[ii];
+      for (int i = i0 + CH; i < bs; ++i) {
+        T acc = (T)0;
+#pragma unroll
+        for (int kk = 0; kk < CH; ++kk) acc += s_t[kk][i - i0] * x[kk];
+        b[i] -= acc;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <typename T> struct KindOf;
 template <> struct KindOf<float> { static constexpr int value = F32; };
 template <> struct KindOf<double> { static constexpr int value = F64; };
@@ -1147,6 +1224,8 @@ template <typename T> struct Workspace {
   // kPlanSpan-wide piece of the step's block; the last set: blocked() itself (one stream).
   SwapPlan* plan[2 * kMaxSub + 1];
   T* linv[2 * kMaxSub + 1];
+  int* linv_flag[2 * kMaxSub + 1];  // set by lu_inverse_guard: solve by substitution, linv holds the identity
+  double inverse_limit;
 };
 constexpr int kOwnScratch = 2 * kMaxSub;
 
@@ -1240,18 +1319,26 @@ inline bool recursive_inverse_enabled() {
   }();
   return on;
 }
-template <typename T> hipError_t make_inverse(const T* L, int64_t ldl, int64_t bs, T* X, hipStream_t s) {
+template <typename T>
+hipError_t make_inverse(const T* L, int64_t ldl, int64_t bs, T* X, int* flag, double limit, hipStream_t s) {
   if ((bs == 64 || bs == 128 || bs == 256) && recursive_inverse_enabled()) {
     hipLaunchKernelGGL(lu_trtri_diag<T>, dim3((unsigned)(bs / kInvCols)), dim3(64), 0, s, L, ldl, (int)bs, X);
     for (int h = kInvCols; h < bs; h *= 2)
       hipLaunchKernelGGL(lu_trtri_merge<T>, dim3((unsigned)(bs / 64)), dim3(256), 0, s, L, ldl, (int)bs, h, X);
-    return hipGetLastError();
+  } else {
+    hipLaunchKernelGGL(lu_trtri<T>, dim3((unsigned)((bs + kInvCols - 1) / kInvCols)), dim3(256), 0, s, L, ldl, (int)bs, X);
   }
-  hipLaunchKernelGGL(lu_trtri<T>, dim3((unsigned)((bs + kInvCols - 1) / kInvCols)), dim3(256), 0, s, L, ldl, (int)bs, X);
+  hipLaunchKernelGGL(lu_inverse_guard<T>, dim3(1), dim3(256), 0, s, X, (int)bs, limit, flag);
   return hipGetLastError();
 }
 template <typename T> bool inverse_applies(int64_t bs) { return bs > 32 && bs <= kPlanSpan && bs <= gemm_tile_rows<T>(); }
-template <typename T> hipError_t apply_inverse(const T* X, int64_t bs, T* B, int64_t ldb, int64_t ncols, hipStream_t s) {
+template <typename T>
+hipError_t apply_inverse(const T* X, const int* flag, const T* L, int64_t ldl, int64_t bs, T* B, int64_t ldb, int64_t ncols,
+                         hipStream_t s) {
+  if (ncols <= 0) return hipSuccess;
+  hipLaunchKernelGGL(lu_subst_flagged<T>, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, s, flag, L, ldl, (int)bs, B, ldb,
+                     (int)ncols);
+  LU_TRY(hipGetLastError());
   return gemm_assign<T>(bs, ncols, bs, X, bs, B, ldb, B, ldb, s);
 }
 
@@ -1310,8 +1397,8 @@ hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows
       T* A21 = A + (k + bs) + k * ld;
       T* A22 = A + (k + bs) + (k + bs) * ld;
       if (inverse_applies<T>(bs)) {                                    // (:492)
-        LU_TRY(make_inverse<T>(A11, ld, bs, w.linv[kOwnScratch], s));
-        LU_TRY(apply_inverse<T>(w.linv[kOwnScratch], bs, A12, ld, tsize, s));
+        LU_TRY(make_inverse<T>(A11, ld, bs, w.linv[kOwnScratch], w.linv_flag[kOwnScratch], w.inverse_limit, s));
+        LU_TRY(apply_inverse<T>(w.linv[kOwnScratch], w.linv_flag[kOwnScratch], A11, ld, bs, A12, ld, tsize, s));
       } else {
         LU_TRY(trsm_unit_lower<T>(A11, A12, ld, bs, tsize, s));
       }
@@ -1399,6 +1486,7 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
     const int nsub = (int)((bs + kPlanSpan - 1) / kPlanSpan);
     SwapPlan* const* plan = &w.plan[(step & 1) * kMaxSub];
     T* const* linv = &w.linv[(step & 1) * kMaxSub];
+    int* const* linv_flag = &w.linv_flag[(step & 1) * kMaxSub];
     auto sub_begin = [&](int i) { return (int64_t)i * kPlanSpan; };
     auto sub_size = [&](int i) { return std::min<int64_t>(kPlanSpan, bs - sub_begin(i)); };
     const bool planned = bs > 32;
@@ -1410,7 +1498,7 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
     if (trows > 0)
       for (int i = 0; i < nsub; ++i)
         if (inverse_applies<T>(sub_size(i)))
-          LU_TRY(make_inverse<T>(A + (k + sub_begin(i)) * (ld + 1), ld, sub_size(i), linv[i], pan));
+          LU_TRY(make_inverse<T>(A + (k + sub_begin(i)) * (ld + 1), ld, sub_size(i), linv[i], linv_flag[i], w.inverse_limit, pan));
     LU_TRY(hipEventRecord(st.factored, pan));
     LU_TRY(hipStreamWaitEvent(upd, st.factored, 0));
     // the step's transpositions, in order, on `ncols` columns
@@ -1425,7 +1513,7 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
       for (int i = 0; i < nsub; ++i) {
         const int64_t o = sub_begin(i), sb = sub_size(i);
         const T* L = A + (k + o) * (ld + 1);
-        if (inverse_applies<T>(sb)) LU_TRY(apply_inverse<T>(linv[i], sb, A12 + o, ld, ncols, upd));
+        if (inverse_applies<T>(sb)) LU_TRY(apply_inverse<T>(linv[i], linv_flag[i], L, ld, sb, A12 + o, ld, ncols, upd));
         else LU_TRY(trsm_unit_lower<T>(L, A12 + o, ld, sb, ncols, upd));
         if (o + sb < bs) LU_TRY(gemm_minus3<T>(bs - o - sb, ncols, sb, L + sb, ld, A12 + o, ld, A12 + o + sb, ld, upd));
       }
@@ -1536,7 +1624,7 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   // Layout of the scratch buffer.  Everything the fused base case exchanges through lies at
   // offsets that do not depend on the matrix: a word of the exchange area only ever holds
   // (payload, generation) pairs, so a stale one can never show the current generation.
-  const size_t off_side = 64;  // first_zero, nswaps, error live in the first 64 bytes
+  const size_t off_side = 128;  // first_zero, nswaps, error and the inverse flags live in the first 128 bytes
   const size_t off_tops = off_side + round64(sizeof(Side<T>));
   const size_t off_slots = (off_tops + round64(2 * sizeof(BaseTop<T>)) + 1023) / 1024 * 1024;
   const size_t off_plan = off_slots + 2 * (size_t)kMaxFusedParts * sizeof(BaseSlot<T>);
@@ -1577,10 +1665,14 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   for (int i = 0; i < kSets; ++i) {
     w.plan[i] = reinterpret_cast<SwapPlan*>(p + off_plan + i * round64(sizeof(SwapPlan)));
     w.linv[i] = reinterpret_cast<T*>(p + off_linv + i * round64((size_t)kPlanSpan * kPlanSpan * sizeof(T)));
+    w.linv_flag[i] = reinterpret_cast<int*>(p) + 8 + i;
   }
+  static_assert(8 + kSets <= 32, "the inverse flags must fit the 128-byte header");
+  w.inverse_limit = kInverseGrowthLimit;
+  if (const char* e = getenv("EIGAMD_LU_INVERSE_LIMIT")) w.inverse_limit = atof(e);  // 0: always substitute (tests)
   w.partials = reinterpret_cast<Candidate<T>*>(p + off_partials);
   w.slots = reinterpret_cast<BaseSlot<T>*>(p + off_slots);
-  LU_TRY(hipMemsetAsync(p, 0, 64, s));  // error flag of the fused base case
+  LU_TRY(hipMemsetAsync(p, 0, 128, s));  // error flag of the fused base case, inverse flags
   LU_TRY(hipMemsetAsync(w.first_zero, 0xFF, sizeof(int), s));  // -1
   LU_TRY(hipMemsetAsync(w.nswaps, 0, sizeof(int), s));
   int per_cu = 0, total_cus = 0;

@@ -145,3 +145,62 @@ def test_host_entry_runs_again_without_the_fused_base_case():
         t2, nb2, r2 = ealu.blocked_lu(a2)
     check_against_oracle(a, a1, t1, a2, t2, exact_pivots=True)
     assert nb1 == nb2 and r1 == r2 == -1
+
+
+def steep_lower_times_upper(n, rng, dt):
+    """A = L U with L unit lower, -0.9 everywhere below the diagonal (inv(L) has entries up to
+    0.9 * 1.9^(n-2)), and U a random upper triangle with a dominant diagonal: the diagonal entry
+    is the strict maximum of every column, so partial pivoting exchanges nothing at first and
+    the unit triangles the factorisation solves with are (perturbations of) L's blocks."""
+    l = np.tril(-0.9 * np.ones((n, n)), -1) + np.eye(n)
+    u = np.triu(rng.uniform(-1, 1, (n, n)), 1) + np.diag(4.0 + rng.uniform(0, 1, n))
+    return np.asfortranarray(l @ u).astype(dt)
+
+
+@pytest.mark.parametrize("dt,n", [(np.float64, 600), (np.float64, 2304), (np.float32, 600)])
+def test_ill_conditioned_unit_triangle_inside_lu(dt, n):
+    """The factors of such a matrix are not determined to working precision (the oracle and the
+    device return different, equally valid ones), the residual is: test/lu.cpp:168's criterion
+    for both, and the same criterion failing by orders of magnitude once every solve multiplies
+    by the explicit inverse (guard switched off)."""
+    rng = np.random.default_rng(n)
+    a = steep_lower_times_upper(n, rng, dt)
+    eps = np.finfo(dt).eps
+    a1, a2, a3 = a.copy(order="F"), a.copy(order="F"), a.copy(order="F")
+    t1, nb1, r1 = oracle_lu(a1)
+    t2, nb2, r2 = ealu.blocked_lu(a2)
+    res_or, res_dev = residual(a, a1, t1), residual(a, a2, t2)
+    with env(EIGAMD_LU_INVERSE_LIMIT="inf"):
+        t3, nb3, r3 = ealu.blocked_lu(a3)
+    res_inv = residual(a, np.nan_to_num(a3, nan=0.0, posinf=0.0, neginf=0.0), t3)
+    print(f"{dt.__name__} {n}: residual / (eps n): oracle {res_or / eps / n:.3g}, device {res_dev / eps / n:.3g}, "
+          f"device with explicit inverses only {res_inv / eps / n:.3g}")
+    check_structure(a2, t2, n, n)
+    assert res_dev <= 8 * eps * n and res_or <= 8 * eps * n
+    assert res_inv > 1e3 * res_dev
+
+
+@pytest.mark.parametrize("dt,n", [(np.float64, 64), (np.float64, 200), (np.float64, 512), (np.float32, 100)])
+def test_growth_matrix(dt, n):
+    """Wilkinson's example: 1 on the diagonal and in the last column, -1 below the diagonal.  No
+    exchanges, L = the lower part, the last column of U doubles from row to row."""
+    a = np.asfortranarray(np.tril(-np.ones((n, n)), -1) + np.eye(n)).astype(dt)
+    a[:, -1] = 1.0
+    a1, a2 = a.copy(order="F"), a.copy(order="F")
+    t1, nb1, r1 = oracle_lu(a1)
+    t2, nb2, r2 = ealu.blocked_lu(a2)
+    assert np.array_equal(t1, t2) and nb1 == nb2 == 0
+    assert np.array_equal(a1, a2)
+    assert a2[-1, -1] == dt(2.0) ** (n - 1)
+
+
+def test_substitution_path_on_ordinary_matrices():
+    """Every solve of the blocked LU through the substitution kernel (limit 0) against the oracle."""
+    for dt in (np.float64, np.float32):
+        for (m, n) in [(700, 700), (2100, 2100)]:
+            a = eigen_amd.fill_uniform_host(dt, m, n, 5 + m)
+            a1, a2 = a.copy(order="F"), a.copy(order="F")
+            t1, nb1, r1 = oracle_lu(a1)
+            with env(EIGAMD_LU_INVERSE_LIMIT=0):
+                t2, nb2, r2 = ealu.blocked_lu(a2)
+            check_against_oracle(a, a1, t1, a2, t2, exact_pivots=dt == np.float64)
