@@ -696,6 +696,9 @@ int eigamd_gemm_dev(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k
   call.A = d_a; call.lda = lda;
   call.B = d_b; call.ldb = ldb;
   call.C = d_c; call.ldc = ldc;
+  // EIGAMD_GEMM_ATOMIC=1 (experiments): beta == 1 products of the real kinds add into C at the memory side
+  static const bool atomic = [] { const char* e = getenv("EIGAMD_GEMM_ATOMIC"); return e && atoi(e) != 0; }();
+  call.atomic_c = atomic;
   HIP_TRY(launch(call, static_cast<hipStream_t>(stream)));
   return EIGAMD_OK;
 }

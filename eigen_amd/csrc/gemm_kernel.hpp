@@ -55,6 +55,12 @@ struct GemmParams {
   int k_chunk;            // k in [s * k_chunk, min(K, (s + 1) * k_chunk)) (k_chunk a multiple of the k-tile)
   int64_t split_stride;   // and writes its product to C + s * split_stride (elements): partial sums that
                           // splitk_reduce_kernel adds up.  tri and ktri must be 0 then.
+  int atomic_c;           // real kinds, beta == 1 only: C += alpha * acc by one floating-point atomic add per
+                          // element, executed at the memory side, instead of load / add / store.  Each element
+                          // receives exactly one add, so the result is the same bits on every run (and the same
+                          // bits as the load / add / store form: one rounding of c + alpha * acc either way), but
+                          // no wavefront ever waits for C: a short reduction (the k = 256 ... 1024 trailing updates
+                          // of the LU) no longer pays the latency of a whole C tile per workgroup.
 };
 
 // Tile geometry per scalar kind.  WM x WN wavefronts per workgroup, each owning
@@ -419,7 +425,7 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
   // Epilogue state, set up in front of the main loop because the first loads of C are issued
   // from inside it.  C = alpha * acc + beta * C; beta == 0 never reads C
   // (blas/level3_impl.h:64: NaN/Inf in C must not propagate).
-  const bool use_c = p.beta[0] != 0.0 || p.beta[1] != 0.0;
+  const bool use_c = (p.beta[0] != 0.0 || p.beta[1] != 0.0) && !p.atomic_c;
   // Triangular destinations (the symmetric rank-k update): elements outside the triangle are
   // neither read nor written; only the epilogue knows about it.
   auto in_tri = [&](int row, int col) {
@@ -553,6 +559,21 @@ __global__ void __launch_bounds__(Geometry<KIND>::THREADS, Geometry<KIND>::MIN_W
   const Real alr = (Real)p.alpha[0], ali = (Real)p.alpha[1];
   const Real ber = (Real)p.beta[0], bei = (Real)p.beta[1];
   const Real sgn = p.conj_a ? (Real)-1 : (Real)1;
+  if constexpr (!T::kCplx) {
+    if (p.atomic_c) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int r = 0; r < T::NACC; ++r) {
+            const int nn = j * TM + acc_row<KIND>(r, 0);
+            if ((!GUARD || (mrow + i * TM < mrem && nrow + nn < nrem)) && in_tri(m0 + mrow + i * TM, n0 + nrow + nn))
+              unsafeAtomicAdd(&cbase[i * TM + (int64_t)nn * p.ldc], alr * acc[j][i][0][r]);
+          }
+      return;
+    }
+  }
   if (use_c) {
     if (!c0_loaded) load_group(0, cv[0]);
 #pragma unroll

@@ -28,6 +28,9 @@ struct GemmCall {
   // place of splitk_workspace(): the launch path then allocates nothing.
   void* partials = nullptr;
   size_t partials_bytes = 0;
+  // Real kinds, beta == 1: accumulate into C with memory-side atomic adds (GemmParams::atomic_c).  C must
+  // be ordinary device memory (hipMalloc); ignored for the complex kinds and for other beta.
+  bool atomic_c = false;
 };
 
 // Block-to-tile mapping knobs; the defaults are what the shipped library uses, the
@@ -114,6 +117,7 @@ static hipError_t launch_region(const GemmCall& c, int64_t r0, int64_t c0, int64
   p.tri = c.tri; p.tri_r0 = (int)r0; p.tri_c0 = (int)c0;
   p.ktri = c.ktri;
   p.splits = splits; p.k_chunk = k_chunk; p.split_stride = rows * cols;
+  p.atomic_c = (c.atomic_c && !Traits<KIND>::kCplx && c.beta[0] == 1.0 && c.beta[1] == 0.0 && splits <= 1) ? 1 : 0;
   if (splits > 1) {  // plain partial products, dense, one after the other
     p.C = partials; p.ldc = rows;
     p.alpha[0] = 1.0; p.alpha[1] = 0.0; p.beta[0] = 0.0; p.beta[1] = 0.0;

@@ -867,6 +867,23 @@ __global__ void lu_trsm_small(const T* __restrict__ L, int64_t ldl, T* __restric
     if (i < jb) col[i] = x[i];
 }
 
+// max|x| over the entries a kernel of the inversion writes, folded into one word per inverse: the
+// bit pattern of a non-negative double orders like the number itself (NaN above infinity), so an
+// integer atomicMax does it.  lu_inverse_finish reads and resets the word.
+__device__ __forceinline__ void note_inverse_max(unsigned long long* gmax, double local_abs_max) {
+  unsigned long long b = (unsigned long long)__double_as_longlong(fabs(local_abs_max));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_down(b, off, 64);
+    b = o > b ? o : b;
+  }
+  if ((threadIdx.x & 63) == 0 && b != 0) atomicMax(gmax, b);
+}
+__device__ __forceinline__ double abs_max2(double m, double v) {
+  const double a = fabs(v);
+  return (a > m || a != a) ? a : m;
+}
+
 // X = L^-1 for the unit lower triangle L of a bs x bs block (bs <= kPlanSpan), written as a
 // full bs x bs matrix (zeros above the diagonal) with leading dimension bs.  A workgroup
 // owns 32 columns of X, kept in LDS, and walks down the rows 32 at a time: first the part of
@@ -875,7 +892,8 @@ __global__ void lu_trsm_small(const T* __restrict__ L, int64_t ldl, T* __restric
 // per column.
 constexpr int kInvCols = 32;
 template <typename T>
-__global__ void __launch_bounds__(256) lu_trtri(const T* __restrict__ L, int64_t ldl, int bs, T* __restrict__ X) {
+__global__ void __launch_bounds__(256) lu_trtri(const T* __restrict__ L, int64_t ldl, int bs, T* __restrict__ X,
+                                                unsigned long long* __restrict__ gmax) {
   __shared__ T s_x[kInvCols][kPlanSpan + 1];   // s_x[c][i]: row i of this workgroup's column c
   __shared__ T s_acc[kInvCols][kInvCols + 1];  // s_acc[c][i - i0]
   __shared__ T s_d[kInvCols][kInvCols + 1];    // s_d[k - i0][i - i0] = L(i, k) of the diagonal block
@@ -927,10 +945,15 @@ __global__ void __launch_bounds__(256) lu_trtri(const T* __restrict__ L, int64_t
     }
     __syncthreads();
   }
+  double mx = 0.0;
   for (int idx = threadIdx.x; idx < kInvCols * bs; idx += 256) {
     const int c = idx / bs, i = idx % bs;
-    if (first + c < bs) X[i + (int64_t)(first + c) * bs] = s_x[c][i];
+    if (first + c < bs) {
+      X[i + (int64_t)(first + c) * bs] = s_x[c][i];
+      mx = abs_max2(mx, (double)s_x[c][i]);
+    }
   }
+  note_inverse_max(gmax, mx);
 }
 
 // The same inverse by block recursion, for bs = 64, 128 or 256 (the usual panel width):
@@ -943,7 +966,8 @@ __global__ void __launch_bounds__(256) lu_trtri(const T* __restrict__ L, int64_t
 // bs = 256; the chain is 4 short launches against one launch whose first workgroup walks all
 // rows (0.29 ms at bs = 256).
 template <typename T>
-__global__ void __launch_bounds__(64) lu_trtri_diag(const T* __restrict__ L, int64_t ldl, int bs, T* __restrict__ X) {
+__global__ void __launch_bounds__(64) lu_trtri_diag(const T* __restrict__ L, int64_t ldl, int bs, T* __restrict__ X,
+                                                    unsigned long long* __restrict__ gmax) {
   __shared__ T s_d[kInvCols][kInvCols + 1];  // s_d[k][i] = L(i, k) of the diagonal block, i > k
   const int first = blockIdx.x * kInvCols;
   for (int idx = threadIdx.x; idx < kInvCols * kInvCols; idx += 64) {
@@ -951,6 +975,7 @@ __global__ void __launch_bounds__(64) lu_trtri_diag(const T* __restrict__ L, int
     s_d[kk][ii] = ii > kk ? L[(first + ii) + (int64_t)(first + kk) * ldl] : (T)0;
   }
   __syncthreads();
+  double mx = 0.0;
   if (threadIdx.x < kInvCols) {
     const int c = threadIdx.x;
     T* col = X + (int64_t)(first + c) * bs;
@@ -965,13 +990,18 @@ __global__ void __launch_bounds__(64) lu_trtri_diag(const T* __restrict__ L, int
       x[ii] = ii < c ? (T)0 : (ii == c ? (T)1 : -v);
     }
 #pragma unroll
-    for (int ii = 0; ii < kInvCols; ++ii) col[first + ii] = x[ii];
+    for (int ii = 0; ii < kInvCols; ++ii) {
+      col[first + ii] = x[ii];
+      mx = abs_max2(mx, (double)x[ii]);
+    }
   }
+  note_inverse_max(gmax, mx);  // (outside the branch: the shuffles of the reduction involve every lane)
 }
 
 constexpr int kMergeRows = 32, kMergeK = 16, kMergeMaxH = 128;
 template <typename T>
-__global__ void __launch_bounds__(256) lu_trtri_merge(const T* __restrict__ L, int64_t ldl, int bs, int h, T* __restrict__ X) {
+__global__ void __launch_bounds__(256) lu_trtri_merge(const T* __restrict__ L, int64_t ldl, int bs, int h, T* __restrict__ X,
+                                                      unsigned long long* __restrict__ gmax) {
   __shared__ __attribute__((aligned(16))) T s_t[kMergeRows][kMergeMaxH + 2];   // T = inv(B)(rows, :) * C
   __shared__ __attribute__((aligned(16))) T s_b[kMergeK][kMergeMaxH + 2];      // k-chunk of the right-hand factor
   __shared__ T s_a[kMergeRows][kMergeK + 1];                                   // k-chunk of the rows of inv(B)
@@ -1047,6 +1077,7 @@ __global__ void __launch_bounds__(256) lu_trtri_merge(const T* __restrict__ L, i
     }
     __syncthreads();
   }
+  double mx = 0.0;
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     if (m < nm) {
@@ -1055,9 +1086,11 @@ __global__ void __launch_bounds__(256) lu_trtri_merge(const T* __restrict__ L, i
         const int j = base + 2 * tj + 32 * m + e;
         X[(r0 + ti) + (int64_t)j * bs] = -acc[0][2 * m + e];
         X[(r0 + ti + 16) + (int64_t)j * bs] = -acc[1][2 * m + e];
+        mx = abs_max2(abs_max2(mx, (double)acc[0][2 * m + e]), (double)acc[1][2 * m + e]);
       }
     }
   }
+  note_inverse_max(gmax, mx);
 }
 
 // ---- when the inverse of a unit lower triangle is not small ------------------------------
@@ -1065,32 +1098,24 @@ __global__ void __launch_bounds__(256) lu_trtri_merge(const T* __restrict__ L, i
 // Partial pivoting bounds |l_ij| by 1, not the entries of inv(L): they are 2 to 4 for the
 // triangles a random matrix produces, but can reach 2^(bs-2) (unit lower with -1 everywhere below
 // the diagonal), and a product with such an inverse loses what the reference's substitution
-// (PartialPivLU.h:492, triangular_solve_matrix) keeps.  lu_inverse_guard measures max|inv(L)| right
-// after the inversion; above `limit` (or not finite) it sets *flag and replaces the inverse by the
+// (PartialPivLU.h:492, triangular_solve_matrix) keeps.  The kernels of the inversion note max|inv(L)|
+// (note_inverse_max); lu_inverse_finish, right after them: above `limit` (or not finite) it sets *flag and replaces the inverse by the
 // identity, and lu_subst_flagged -- launched in front of every product with that inverse, a no-op
 // while the flag is clear -- solves by substitution instead.  The launch sequence is the same
 // either way, so nothing has to come back to the host.
 constexpr double kInverseGrowthLimit = 16.0;
 template <typename T>
-__global__ void __launch_bounds__(256) lu_inverse_guard(T* __restrict__ X, int bs, double limit, int* __restrict__ flag) {
-  __shared__ double s_m[4];
-  double mx = 0.0;
-  for (int idx = threadIdx.x; idx < bs * bs; idx += 256) {
-    const double v = fabs((double)X[idx]);
-    mx = (v > mx || v != v) ? v : mx;
+__global__ void __launch_bounds__(256) lu_inverse_finish(T* __restrict__ X, int bs, double limit,
+                                                         unsigned long long* __restrict__ gmax, int* __restrict__ flag) {
+  __shared__ int s_subst;
+  if (threadIdx.x == 0) {
+    const double mx = __longlong_as_double((long long)*gmax);
+    *gmax = 0;  // for the next inversion that uses this word
+    s_subst = !(mx <= limit);
+    *flag = s_subst;
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const double o = __shfl_down(mx, off, 64);
-    mx = (o > mx || o != o) ? o : mx;
-  }
-  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = mx;
   __syncthreads();
-  mx = s_m[0];
-  for (int w = 1; w < 4; ++w) mx = (s_m[w] > mx || s_m[w] != s_m[w]) ? s_m[w] : mx;
-  const bool subst = !(mx <= limit);
-  if (threadIdx.x == 0) *flag = subst ? 1 : 0;
-  if (subst)
+  if (s_subst)
     for (int idx = threadIdx.x; idx < bs * bs; idx += 256) X[idx] = (idx % bs == idx / bs) ? (T)1 : (T)0;
 }
 
@@ -1143,6 +1168,11 @@ template <> struct KindOf<double> { static constexpr int value = F64; };
 
 template <typename T> hipError_t gemm_minus3(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B,
                                              int64_t ldb, T* C, int64_t ldc, hipStream_t s);
+// EIGAMD_LU_ATOMIC=0: the trailing updates read, add and store C instead of adding at the memory side (experiments).
+inline bool atomic_updates_enabled() {
+  static const bool on = [] { const char* e = std::getenv("EIGAMD_LU_ATOMIC"); return !(e && std::atoi(e) == 0); }();
+  return on;
+}
 
 template <typename T> hipError_t gemm_minus(int64_t m, int64_t n, int64_t k, const T* A, const T* B, T* C, int64_t ld,
                                             hipStream_t s) {
@@ -1157,6 +1187,7 @@ template <typename T> hipError_t gemm_minus3(int64_t m, int64_t n, int64_t k, co
   c.opa = OP_N; c.opb = OP_N;
   c.m = m; c.n = n; c.k = k;
   c.serial_edges = true;   // the look-ahead owns the CU split between its streams
+  c.atomic_c = atomic_updates_enabled() && k >= 512;  // (a k = 256 product is bound by the rate of the atomic adds: 53 against 55 TFLOP/s)
   c.alpha[0] = -1.0; c.alpha[1] = 0.0;
   c.beta[0] = 1.0; c.beta[1] = 0.0;
   c.A = A; c.lda = lda;
@@ -1224,7 +1255,8 @@ template <typename T> struct Workspace {
   // kPlanSpan-wide piece of the step's block; the last set: blocked() itself (one stream).
   SwapPlan* plan[2 * kMaxSub + 1];
   T* linv[2 * kMaxSub + 1];
-  int* linv_flag[2 * kMaxSub + 1];  // set by lu_inverse_guard: solve by substitution, linv holds the identity
+  int* linv_flag[2 * kMaxSub + 1];  // set by lu_inverse_finish: solve by substitution, linv holds the identity
+  unsigned long long* linv_max[2 * kMaxSub + 1];  // max|inv(L)| as the inversion kernels noted it (zero between uses)
   double inverse_limit;
 };
 constexpr int kOwnScratch = 2 * kMaxSub;
@@ -1320,15 +1352,16 @@ inline bool recursive_inverse_enabled() {
   return on;
 }
 template <typename T>
-hipError_t make_inverse(const T* L, int64_t ldl, int64_t bs, T* X, int* flag, double limit, hipStream_t s) {
+hipError_t make_inverse(const T* L, int64_t ldl, int64_t bs, T* X, int* flag, unsigned long long* gmax, double limit,
+                        hipStream_t s) {
   if ((bs == 64 || bs == 128 || bs == 256) && recursive_inverse_enabled()) {
-    hipLaunchKernelGGL(lu_trtri_diag<T>, dim3((unsigned)(bs / kInvCols)), dim3(64), 0, s, L, ldl, (int)bs, X);
+    hipLaunchKernelGGL(lu_trtri_diag<T>, dim3((unsigned)(bs / kInvCols)), dim3(64), 0, s, L, ldl, (int)bs, X, gmax);
     for (int h = kInvCols; h < bs; h *= 2)
-      hipLaunchKernelGGL(lu_trtri_merge<T>, dim3((unsigned)(bs / 64)), dim3(256), 0, s, L, ldl, (int)bs, h, X);
+      hipLaunchKernelGGL(lu_trtri_merge<T>, dim3((unsigned)(bs / 64)), dim3(256), 0, s, L, ldl, (int)bs, h, X, gmax);
   } else {
-    hipLaunchKernelGGL(lu_trtri<T>, dim3((unsigned)((bs + kInvCols - 1) / kInvCols)), dim3(256), 0, s, L, ldl, (int)bs, X);
+    hipLaunchKernelGGL(lu_trtri<T>, dim3((unsigned)((bs + kInvCols - 1) / kInvCols)), dim3(256), 0, s, L, ldl, (int)bs, X, gmax);
   }
-  hipLaunchKernelGGL(lu_inverse_guard<T>, dim3(1), dim3(256), 0, s, X, (int)bs, limit, flag);
+  hipLaunchKernelGGL(lu_inverse_finish<T>, dim3(1), dim3(256), 0, s, X, (int)bs, limit, gmax, flag);
   return hipGetLastError();
 }
 template <typename T> bool inverse_applies(int64_t bs) { return bs > 32 && bs <= kPlanSpan && bs <= gemm_tile_rows<T>(); }
@@ -1397,7 +1430,7 @@ hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows
       T* A21 = A + (k + bs) + k * ld;
       T* A22 = A + (k + bs) + (k + bs) * ld;
       if (inverse_applies<T>(bs)) {                                    // (:492)
-        LU_TRY(make_inverse<T>(A11, ld, bs, w.linv[kOwnScratch], w.linv_flag[kOwnScratch], w.inverse_limit, s));
+        LU_TRY(make_inverse<T>(A11, ld, bs, w.linv[kOwnScratch], w.linv_flag[kOwnScratch], w.linv_max[kOwnScratch], w.inverse_limit, s));
         LU_TRY(apply_inverse<T>(w.linv[kOwnScratch], w.linv_flag[kOwnScratch], A11, ld, bs, A12, ld, tsize, s));
       } else {
         LU_TRY(trsm_unit_lower<T>(A11, A12, ld, bs, tsize, s));
@@ -1498,7 +1531,7 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
     if (trows > 0)
       for (int i = 0; i < nsub; ++i)
         if (inverse_applies<T>(sub_size(i)))
-          LU_TRY(make_inverse<T>(A + (k + sub_begin(i)) * (ld + 1), ld, sub_size(i), linv[i], linv_flag[i], w.inverse_limit, pan));
+          LU_TRY(make_inverse<T>(A + (k + sub_begin(i)) * (ld + 1), ld, sub_size(i), linv[i], linv_flag[i], w.linv_max[(step & 1) * kMaxSub + i], w.inverse_limit, pan));
     LU_TRY(hipEventRecord(st.factored, pan));
     LU_TRY(hipStreamWaitEvent(upd, st.factored, 0));
     // the step's transpositions, in order, on `ncols` columns
@@ -1586,6 +1619,7 @@ hipError_t make_streams(LuStreams& st, int base_workgroups, int per_cu, int* tot
     LU_TRY(hipStreamSynchronize(st.panel));
     LU_TRY(hipStreamDestroy(st.panel));
     st.panel = nullptr;
+
     if (st.update) {
       LU_TRY(hipStreamSynchronize(st.update));
       LU_TRY(hipStreamDestroy(st.update));
@@ -1608,6 +1642,7 @@ hipError_t make_streams(LuStreams& st, int base_workgroups, int per_cu, int* tot
     for (int b = 0; b < total; ++b) (b >= total - want ? pmask : umask)[b / 32] |= 1u << (b % 32);
     LU_TRY(hipExtStreamCreateWithCUMask(&st.panel, (uint32_t)words, pmask.data()));
     LU_TRY(hipExtStreamCreateWithCUMask(&st.update, (uint32_t)words, umask.data()));
+
   }
   st.panel_cus = want;
   if (getenv("EIGAMD_LU_DEBUG")) fprintf(stderr, "eigen_amd LU: panel CUs %d of %d, base-case workgroups %d, %d per CU\n", want, total, base_workgroups, per_cu);
@@ -1624,7 +1659,7 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   // Layout of the scratch buffer.  Everything the fused base case exchanges through lies at
   // offsets that do not depend on the matrix: a word of the exchange area only ever holds
   // (payload, generation) pairs, so a stale one can never show the current generation.
-  const size_t off_side = 128;  // first_zero, nswaps, error and the inverse flags live in the first 128 bytes
+  const size_t off_side = 256;  // first_zero, nswaps, error, the inverse flags and maxima live in the first 256 bytes
   const size_t off_tops = off_side + round64(sizeof(Side<T>));
   const size_t off_slots = (off_tops + round64(2 * sizeof(BaseTop<T>)) + 1023) / 1024 * 1024;
   const size_t off_plan = off_slots + 2 * (size_t)kMaxFusedParts * sizeof(BaseSlot<T>);
@@ -1666,13 +1701,14 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
     w.plan[i] = reinterpret_cast<SwapPlan*>(p + off_plan + i * round64(sizeof(SwapPlan)));
     w.linv[i] = reinterpret_cast<T*>(p + off_linv + i * round64((size_t)kPlanSpan * kPlanSpan * sizeof(T)));
     w.linv_flag[i] = reinterpret_cast<int*>(p) + 8 + i;
+    w.linv_max[i] = reinterpret_cast<unsigned long long*>(p + 128) + i;
   }
-  static_assert(8 + kSets <= 32, "the inverse flags must fit the 128-byte header");
+  static_assert(8 + kSets <= 32 && kSets * 8 <= 128, "the inverse flags and maxima must fit the 256-byte header");
   w.inverse_limit = kInverseGrowthLimit;
   if (const char* e = getenv("EIGAMD_LU_INVERSE_LIMIT")) w.inverse_limit = atof(e);  // 0: always substitute (tests)
   w.partials = reinterpret_cast<Candidate<T>*>(p + off_partials);
   w.slots = reinterpret_cast<BaseSlot<T>*>(p + off_slots);
-  LU_TRY(hipMemsetAsync(p, 0, 128, s));  // error flag of the fused base case, inverse flags
+  LU_TRY(hipMemsetAsync(p, 0, 256, s));  // error flag of the fused base case, inverse flags and maxima
   LU_TRY(hipMemsetAsync(w.first_zero, 0xFF, sizeof(int), s));  // -1
   LU_TRY(hipMemsetAsync(w.nswaps, 0, sizeof(int), s));
   int per_cu = 0, total_cus = 0;
