@@ -20,6 +20,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "gemm_launch.hpp"
@@ -37,6 +38,15 @@ namespace {
 #endif
 constexpr int kRowsPerBlock = EIGAMD_LU_ROWS_PER_BLOCK;  // rows of the panel one workgroup owns
 constexpr int kMaxBase = 16;        // widest unblocked panel (UnBlockedBound, PartialPivLU.h:336)
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant in
+// every iteration, whatever the optimiser thinks of the body's size.
+template <typename F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 template <typename T> struct Candidate {
   T val;    // |a|, or -1 for "no row"
@@ -328,12 +338,12 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
 #else
 #define LU_TICK(i)
 #endif
-  // The registers of a row are rotated by one place per pivot column, so that the pivot column is
-  // always row[0] (a register index must be a constant): during column jj, row[c] holds panel
-  // column (jj + c) % 16; the columns right of jj are row[1 .. 15 - jj], the finished ones behind them.
-  int jj_done = 0;  // rotations so far
-#pragma unroll 1
-  for (int jj = 0; jj < size; ++jj) {
+  // The loop over the pivot columns is unrolled in full (static_for): every register index is a
+  // constant, and column jj updates exactly the columns right of it.
+  bool alive = true;  // false once a workgroup has given up waiting
+  static_for<kMaxBase>([&](auto jj_c) {
+    constexpr int jj = decltype(jj_c)::value;
+    if (jj < size && alive) {
 #ifdef EIGAMD_LU_TIMING
     tprev = wall_clock64();
 #endif
@@ -341,7 +351,7 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
     BaseSlot<T>* buf = slots + (size_t)(G & 1u) * kMaxFusedParts;
     BaseTop<T>* top = tops + (G & 1u);
     // candidate of this workgroup for column jj ("no row" when all its rows are above jj)
-    const T cur = row[0];
+    const T cur = row[jj];
     const bool cand = valid && r >= jj;
     const Candidate<T> best = block_best_all<T>(cand ? (T)fabs(cur) : (T)-1, cand ? r : kNoRow);
     const bool have = best.row != kNoRow;
@@ -358,7 +368,7 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
 #pragma unroll
           for (int c = 0; c < kMaxBase; ++c)
 #pragma unroll
-            for (int w = 0; w < NW; ++w) pub[((jj + c) & (kMaxBase - 1)) * NW + w] = value_word(row[c], w);
+            for (int w = 0; w < NW; ++w) pub[c * NW + w] = value_word(row[c], w);
         }
         __builtin_amdgcn_wave_barrier();
         unsigned long long* mine = reinterpret_cast<unsigned long long*>(buf + blockIdx.x);
@@ -387,7 +397,7 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
 #pragma unroll
         for (int c = 0; c < kMaxBase; ++c)
 #pragma unroll
-          for (int w = 0; w < NW; ++w) pub[((jj + c) & (kMaxBase - 1)) * NW + w] = value_word(row[c], w);
+          for (int w = 0; w < NW; ++w) pub[c * NW + w] = value_word(row[c], w);
       }
       __builtin_amdgcn_wave_barrier();
       if (lane < kMaxBase * NW) put_word(&top->data[lane], pub[lane], G);
@@ -477,8 +487,9 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
     LU_TICK(4)
     if (s_flags & 2) {
       if (threadIdx.x == 0) coherent_store(error, 1);
-      break;
+      alive = false;
     }
+    if (alive) {
     Candidate<T> win;
     win.row = s_win_row;
     const bool zero = (s_flags & 1) != 0;
@@ -491,40 +502,28 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
     if (swap && valid && (r == win.row || r == jj)) {
       const T* src = r == jj ? s_u : s_top;  // (never both: swap means win.row != jj)
 #pragma unroll
-      for (int c = 0; c < kMaxBase; ++c) row[c] = src[(jj + c) & (kMaxBase - 1)];
+      for (int c = 0; c < kMaxBase; ++c) row[c] = src[c];
     }
     if (valid && r > jj) {
-      T l = row[0];
+      T l = row[jj];
       if (!zero) l = l / s_u[jj];  // the reference divides (lu.col(k).tail /= pivot, :389)
-      row[0] = l;
+      row[jj] = l;
 #pragma unroll
-      for (int c = 1; c < kMaxBase; ++c) {
-        const T x = row[c] - l * s_u[(jj + c) & (kMaxBase - 1)];
-        row[c] = c < kMaxBase - jj ? x : row[c];
-      }
+      for (int c = jj + 1; c < kMaxBase; ++c) row[c] -= l * s_u[c];
     }
-    {
-      const T first = row[0];
-#pragma unroll
-      for (int c = 0; c + 1 < kMaxBase; ++c) row[c] = row[c + 1];
-      row[kMaxBase - 1] = first;
-      ++jj_done;
     }
     LU_TICK(5)
     // No barrier here: wavefront 0 rewrites s_u / s_top / s_win_row only after the barrier inside
     // the next column's block_best_all, which every wavefront reaches after this update; and the
     // wavefronts rewrite their block_best_all slots only after the barrier above, behind which
     // nobody reads them any more.
-  }
+    }
+  });
 
   if (valid) {
-    // after `size` rotations (or fewer, when the loop was left early) row[c] is column (done + c) % 16
-    const int done = jj_done;
 #pragma unroll
-    for (int c = 0; c < kMaxBase; ++c) {
-      const int col = (done + c) & (kMaxBase - 1);
-      if (col < jbw) P[r + (int64_t)col * ld] = row[c];
-    }
+    for (int c = 0; c < kMaxBase; ++c)
+      if (c < jbw) P[r + (int64_t)c * ld] = row[c];
   }
 #ifdef EIGAMD_LU_TIMING
   if (blockIdx.x == 0 && threadIdx.x == 0 && (col_global & 1023) == 0)
@@ -549,8 +548,8 @@ __global__ void __launch_bounds__(kSingleThreads)
   __shared__ T s_val[kSingleThreads / 64];
   __shared__ int s_row[kSingleThreads / 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  // row[q][c]: row tid + q * 1024; the columns rotate by one place per pivot column, so that the
-  // pivot column is always c == 0 (see lu_base_fused)
+  // row[q][c]: element c of row tid + q * 1024.  The loop over the pivot columns is unrolled in full,
+  // so that every register index is a constant and column jj updates exactly the columns right of it.
   T row[kSingleRpt][kMaxBase];
 #pragma unroll
   for (int q = 0; q < kSingleRpt; ++q)
@@ -559,87 +558,78 @@ __global__ void __launch_bounds__(kSingleThreads)
       const int r = tid + q * kSingleThreads;
       row[q][c] = (r < rows && c < jbw) ? P[r + (int64_t)c * ld] : (T)0;
     }
-  int done = 0;
-#pragma unroll 1
-  for (int jj = 0; jj < size; ++jj) {
-    T val = (T)-1;
-    int prow = kNoRow;
+  static_for<kMaxBase>([&](auto jj_c) {
+    constexpr int jj = decltype(jj_c)::value;
+    if (jj < size) {
+      T val = (T)-1;
+      int prow = kNoRow;
 #pragma unroll
-    for (int q = 0; q < kSingleRpt; ++q) {
-      const int r = tid + q * kSingleThreads;
-      if (r < rows && r >= jj) {
-        const T v = (T)fabs(row[q][0]);
-        if (better(v, r, val, prow)) { val = v; prow = r; }
-      }
-    }
-    wave_best_to_lane63(val, prow);
-    if (lane == 63) { s_val[wave] = val; s_row[wave] = prow; }
-    __syncthreads();
-    val = s_val[0];
-    prow = s_row[0];
-#pragma unroll
-    for (int w = 1; w < kSingleThreads / 64; ++w)
-      if (better(s_val[w], s_row[w], val, prow)) { val = s_val[w]; prow = s_row[w]; }
-    if (prow == kNoRow) {  // nothing comparable in the column (NaNs): no exchange, pivot = the diagonal entry
-      prow = jj;
-      val = (T)1;
-    }
-    const bool zero = !(val != (T)0);  // exactly zero
-    const bool swap = !zero && prow != jj;
-    // the pivot row (what every row below is updated with) and, for an exchange, panel row jj
-#pragma unroll
-    for (int q = 0; q < kSingleRpt; ++q) {
-      const int r = tid + q * kSingleThreads;
-      if (r == jj) {
-#pragma unroll
-        for (int c = 0; c < kMaxBase; ++c) (swap ? s_top : s_u)[(jj + c) & (kMaxBase - 1)] = row[q][c];
-      } else if (swap && r == prow) {
-#pragma unroll
-        for (int c = 0; c < kMaxBase; ++c) s_u[(jj + c) & (kMaxBase - 1)] = row[q][c];
-      }
-    }
-    __syncthreads();
-    if (tid == 0) {
-      transp[jj] = row_offset + prow;
-      if (zero) atomicCAS(first_zero, -1, col_global + jj);  // keep the FIRST zero pivot (PartialPivLU.h:391-396)
-      else if (swap) atomicAdd(nswaps, 1);
-    }
-#pragma unroll
-    for (int q = 0; q < kSingleRpt; ++q) {
-      const int r = tid + q * kSingleThreads;
-      if (swap && (r == jj || r == prow)) {
-        const T* src = r == jj ? s_u : s_top;
-#pragma unroll
-        for (int c = 0; c < kMaxBase; ++c) row[q][c] = src[(jj + c) & (kMaxBase - 1)];
-      }
-      if (r < rows && r > jj) {
-        T l = row[q][0];
-        if (!zero) l = l / s_u[jj];  // the reference divides (lu.col(k).tail /= pivot, PartialPivLU.h:389)
-        row[q][0] = l;
-#pragma unroll
-        for (int c = 1; c < kMaxBase; ++c) {
-          const T x = row[q][c] - l * s_u[(jj + c) & (kMaxBase - 1)];
-          row[q][c] = c < kMaxBase - jj ? x : row[q][c];
+      for (int q = 0; q < kSingleRpt; ++q) {
+        const int r = tid + q * kSingleThreads;
+        if (r < rows && r >= jj) {
+          const T v = (T)fabs(row[q][jj]);
+          if (better(v, r, val, prow)) { val = v; prow = r; }
         }
       }
-      const T first = row[q][0];
+      wave_best_to_lane63(val, prow);
+      if (lane == 63) { s_val[wave] = val; s_row[wave] = prow; }
+      __syncthreads();
+      val = s_val[0];
+      prow = s_row[0];
 #pragma unroll
-      for (int c = 0; c + 1 < kMaxBase; ++c) row[q][c] = row[q][c + 1];
-      row[q][kMaxBase - 1] = first;
+      for (int w = 1; w < kSingleThreads / 64; ++w)
+        if (better(s_val[w], s_row[w], val, prow)) { val = s_val[w]; prow = s_row[w]; }
+      if (prow == kNoRow) {  // nothing comparable in the column (NaNs): no exchange, pivot = the diagonal entry
+        prow = jj;
+        val = (T)1;
+      }
+      const bool zero = !(val != (T)0);  // exactly zero
+      const bool swap = !zero && prow != jj;
+      // the pivot row (what every row below is updated with) and, for an exchange, panel row jj
+#pragma unroll
+      for (int q = 0; q < kSingleRpt; ++q) {
+        const int r = tid + q * kSingleThreads;
+        if (r == jj) {
+#pragma unroll
+          for (int c = 0; c < kMaxBase; ++c) (swap ? s_top : s_u)[c] = row[q][c];
+        } else if (swap && r == prow) {
+#pragma unroll
+          for (int c = 0; c < kMaxBase; ++c) s_u[c] = row[q][c];
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        transp[jj] = row_offset + prow;
+        if (zero) atomicCAS(first_zero, -1, col_global + jj);  // keep the FIRST zero pivot (PartialPivLU.h:391-396)
+        else if (swap) atomicAdd(nswaps, 1);
+      }
+#pragma unroll
+      for (int q = 0; q < kSingleRpt; ++q) {
+        const int r = tid + q * kSingleThreads;
+        if (swap && (r == jj || r == prow)) {
+          const T* src = r == jj ? s_u : s_top;
+#pragma unroll
+          for (int c = 0; c < kMaxBase; ++c) row[q][c] = src[c];
+        }
+        if (r < rows && r > jj) {
+          T l = row[q][jj];
+          if (!zero) l = l / s_u[jj];  // the reference divides (lu.col(k).tail /= pivot, PartialPivLU.h:389)
+          row[q][jj] = l;
+#pragma unroll
+          for (int c = jj + 1; c < kMaxBase; ++c) row[q][c] -= l * s_u[c];
+        }
+      }
+      // s_val / s_row are rewritten before the next column's first barrier and were last read before
+      // this column's second one; s_u / s_top are rewritten after the next column's first barrier.
     }
-    ++done;
-    // s_val / s_row are rewritten before the next column's first barrier and were last read before
-    // this column's second one; s_u / s_top are rewritten after the next column's first barrier.
-  }
+  });
 #pragma unroll
   for (int q = 0; q < kSingleRpt; ++q) {
     const int r = tid + q * kSingleThreads;
     if (r < rows) {
 #pragma unroll
-      for (int c = 0; c < kMaxBase; ++c) {
-        const int col = (done + c) & (kMaxBase - 1);
-        if (col < jbw) P[r + (int64_t)col * ld] = row[q][c];
-      }
+      for (int c = 0; c < kMaxBase; ++c)
+        if (c < jbw) P[r + (int64_t)c * ld] = row[q][c];
     }
   }
 }
