@@ -106,6 +106,19 @@ lib.eigamd_trmm_dev.restype = ctypes.c_int
 lib.eigamd_trmm_dev.argtypes = [ctypes.c_int] * 5 + [_i64, _i64, _vp, _vp, _i64, _vp, _i64, _vp]
 lib.eigamd_trsm_dev.restype = ctypes.c_int
 lib.eigamd_trsm_dev.argtypes = [ctypes.c_int] * 5 + [_i64, _i64, _vp, _vp, _i64, _vp, _i64, _vp]
+_pp = ctypes.POINTER(ctypes.c_void_p)
+lib.eigamd_pgemm_host.restype = ctypes.c_int
+lib.eigamd_pgemm_host.argtypes = [ctypes.c_int] * 3 + [_i64] * 3 + [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, ctypes.c_int,
+                                  ctypes.c_int, _i64, _vp, ctypes.c_int]
+lib.eigamd_pgemm_create.restype = ctypes.c_int
+lib.eigamd_pgemm_create.argtypes = [ctypes.c_int] * 3 + [_i64] * 3 + [ctypes.c_int, ctypes.c_int, _i64, _vp, ctypes.c_int, _pp]
+for _name, _args in (("fill", [_vp, ctypes.c_int, ctypes.c_uint64]), ("scatter", [_vp, ctypes.c_int, _vp, _i64]),
+                     ("gather", [_vp, ctypes.c_int, _vp, _i64]), ("run", [_vp, _vp, _vp]), ("sync", [_vp]), ("destroy", [_vp]),
+                     ("local", [_vp, ctypes.c_int, ctypes.c_int, _pp, ctypes.POINTER(_i64), ctypes.POINTER(_i64),
+                                ctypes.POINTER(_i64), _i32p])):
+    _f = getattr(lib, "eigamd_pgemm_" + _name)
+    _f.restype = ctypes.c_int
+    _f.argtypes = _args
 lib.eigamd_last_error.restype = ctypes.c_char_p
 lib.eigamd_last_error.argtypes = []
 lib.eigamd_device_ok.restype = ctypes.c_int

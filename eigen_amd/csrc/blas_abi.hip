@@ -432,6 +432,7 @@ int op_of(char ch) {  // blas/common.h:47-50
 }  // namespace
 
 namespace eigamd {
+int abi_fail(int code, const std::string& what) { return fail(code, what); }  // for the other translation units of the ABI
 namespace {
 struct EdgeStreams {
   std::mutex mu;

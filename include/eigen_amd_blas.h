@@ -102,6 +102,43 @@ int eigamd_gemm_mixed_dev(int dtype, int a_is_real, int b_is_real, int opa, int 
                           const void* alpha, const void* d_a, int64_t lda, const void* d_b, int64_t ldb, const void* beta,
                           void* d_c, int64_t ldc, void* stream);
 
+/* ---- the product over several GPUs of one node ---------------------------------------
+ * In the reference the split of a product over the cores is invisible to the caller
+ * (parallelize_gemm, Eigen/src/Core/products/Parallelizer.h:101-176, reached from
+ * GeneralMatrixMatrix.h:510-511): every thread owns a column slab of C, all share one packed
+ * panel of A per k-block (GeneralMatrixMatrix.h:86-158).  Here one process drives an
+ * nprow x npcol grid of devices: A, B and C are dealt out 2-D block-cyclically (block nb), the
+ * reduction runs over k-panels of nb, and per panel the owners' pieces of A travel along grid
+ * rows and those of B along grid columns, one panel ahead of the local products (SUMMA; K is
+ * never split, so nothing is reduced).
+ *
+ * eigamd_pgemm_host: C <- alpha op(A) op(B) + beta C on host matrices (column-major, any
+ * leading dimensions), scattered to the grid, multiplied, gathered.  `devices`: nprow * npcol
+ * device ordinals in row-major grid order, or NULL for 0, 1, ...; an ordinal may repeat
+ * ("virtual grid": several ranks on one device, for checking the schedule on one GPU).
+ * `transport`: 0 = one peer copy per receiver (hipMemcpyPeerAsync, DMA engines over the xGMI
+ * link of each pair), 1 = ncclBroadcast on row / column communicators (RCCL; one device per rank).
+ *
+ * The handle form keeps the distributed operands in HBM between calls (what a benchmark times):
+ * create, fill with the synthetic operands (equal, element for element, to
+ * eigamd_fill_uniform_dev of the stored matrix) or scatter / gather host matrices (`which`:
+ * 0 = A, 1 = B, 2 = C, each in the orientation it is stored in), run (asynchronous), sync.
+ * eigamd_pgemm_local exposes a rank's local part for inspection. */
+typedef struct eigamd_pgemm eigamd_pgemm;
+int eigamd_pgemm_host(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k, const void* alpha, const void* a,
+                      int64_t lda, const void* b, int64_t ldb, const void* beta, void* c, int64_t ldc, int nprow, int npcol,
+                      int64_t nb, const int* devices, int transport);
+int eigamd_pgemm_create(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k, int nprow, int npcol, int64_t nb,
+                        const int* devices, int transport, eigamd_pgemm** handle);
+int eigamd_pgemm_fill(eigamd_pgemm* handle, int which, uint64_t seed);
+int eigamd_pgemm_scatter(eigamd_pgemm* handle, int which, const void* host, int64_t ld);
+int eigamd_pgemm_gather(eigamd_pgemm* handle, int which, void* host, int64_t ld);
+int eigamd_pgemm_run(eigamd_pgemm* handle, const void* alpha, const void* beta);
+int eigamd_pgemm_sync(eigamd_pgemm* handle);
+int eigamd_pgemm_local(eigamd_pgemm* handle, int which, int rank, void** ptr, int64_t* rows, int64_t* cols, int64_t* ld,
+                       int* device);
+int eigamd_pgemm_destroy(eigamd_pgemm* handle);
+
 /* ---- synthetic operands ------------------------------------------------------
  * U[-1,1) entries from a counter-based generator: element (i,j) depends only on
  * (seed, i, j), so host and device produce bit-identical matrices without a
