@@ -115,7 +115,9 @@ def cpu_baseline(args):
     if ref is not None:
         ref.ref_set_threads(threads)
         secs = ref.ref_bench_gemm(1, n, n, n, 2)
-        return {"value": round(2.0 * n ** 3 / secs / 1e12, 4), "unit": "TFLOP/s", "cores": int(ref.ref_num_threads()),
+        # the reference's own default case (bench/bench_gemm.cpp:179: 2048^3, double) beside it
+        secs_2048 = ref.ref_bench_gemm(1, 2048, 2048, 2048, 3)
+        return {"eigen_cpu_2048_tflops": round(2.0 * 2048 ** 3 / secs_2048 / 1e12, 4), "value": round(2.0 * n ** 3 / secs / 1e12, 4), "unit": "TFLOP/s", "cores": int(ref.ref_num_threads()),
                 "kind": "reference",
                 "sample": f"Eigen operator* (c.noalias()+=a*b) double {n}^3, best of 2, {ref.variant} "
                           f"[{ref.ref_simd().decode()}], {2.0 * n ** 3 / (2.0 * 16384 ** 3):.4f} of one step's flops",
@@ -241,7 +243,10 @@ def mixed_measurement(n):
 
 def lu_measurement(n):
     """PartialPivLU-equivalent factorisation (eigamd_getrf_dev) of an n x n double matrix
-    resident in HBM; 2/3 n^3 flop.  The trailing updates run on the GEMM kernel."""
+    resident in HBM; 2/3 n^3 flop.  The trailing updates run on the GEMM kernel.  What was timed
+    is checked: transpositions in range, |l_ij| <= 1, and the reference's own acceptance
+    criterion (test/lu.cpp:168, P*A = L*U to 8 * eps * n) on sampled block rows."""
+    import numpy as np
     import torch
     import eigen_amd
     from eigen_amd.device import DeviceMatrix
@@ -252,10 +257,59 @@ def lu_measurement(n):
         a.fill_uniform(77)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        _, _, first_zero = ealu.getrf_dev(a)
+        transp, _, first_zero = ealu.getrf_dev(a)
         torch.cuda.synchronize()
         best = min(best, time.perf_counter() - t0)
-    return {f"lu_{n}_f64_seconds": round(best, 4), f"lu_{n}_f64_tflops": round(2.0 / 3.0 * n ** 3 / best / 1e12, 2)}
+    t = transp.cpu().numpy()
+    ok = first_zero == -1 and bool((t >= np.arange(n)).all() and (t < n).all())
+    perm = np.arange(n)
+    for i, p in enumerate(t):
+        if p != i:
+            perm[i], perm[p] = perm[p], perm[i]
+    lu = a.as_strided()
+    a0 = DeviceMatrix(n, n, eigen_amd.F64).fill_uniform(77).as_strided()
+    u = torch.triu(lu)
+    cols = torch.arange(n, device="cuda")
+    worst, lmax, block = 0.0, 0.0, 128
+    for r0 in sorted({0, n // 3, n // 2 + 64, n - block}):
+        rows = torch.arange(r0, r0 + block, device="cuda")
+        lr = torch.where(cols[None, :] < rows[:, None], lu[rows], torch.zeros((), dtype=lu.dtype, device="cuda"))
+        lmax = max(lmax, float(lr.abs().max()))
+        lr[torch.arange(block, device="cuda"), rows] = 1.0
+        pa = a0[torch.as_tensor(perm[r0:r0 + block], device="cuda")]
+        worst = max(worst, float(torch.linalg.norm(pa - lr @ u) / torch.linalg.norm(pa)))
+    eps = 2.0 ** -52
+    return {f"lu_{n}_f64_seconds": round(best, 4), f"lu_{n}_f64_tflops": round(2.0 / 3.0 * n ** 3 / best / 1e12, 2),
+            f"lu_{n}_residual_over_eps_n": round(worst / (eps * n), 4), f"lu_{n}_residual_limit": 8.0,
+            f"lu_{n}_max_abs_l": round(lmax, 6), f"lu_{n}_checks_ok": bool(ok and worst <= 8 * eps * n and lmax <= 1.0)}
+
+
+def variant_measurements():
+    """Device-resident C += op(A)*op(B) at the configured sizes for the transpose / conjugate forms
+    (TFLOP/s, best of 3): dgemm / sgemm 16384^3 NN TN NT TT, zgemm / cgemm 8192^3 NN TN NC CC."""
+    import torch
+    from eigen_amd.device import DeviceMatrix, gemm_dev
+    out = {}
+    for dtype, n, forms in (("f64", 16384, ("TN", "NT", "TT")), ("f32", 16384, ("TN", "NT", "TT")),
+                            ("c64", 8192, ("TN", "NC", "CC")), ("c32", 8192, ("TN", "NC", "CC"))):
+        kind = KIND[dtype]
+        a = DeviceMatrix(n, n, kind).fill_uniform(1)
+        b = DeviceMatrix(n, n, kind).fill_uniform(2)
+        c = DeviceMatrix(n, n, kind).fill_uniform(3)
+        flops = (8.0 if kind >= 2 else 2.0) * n ** 3
+        for f in forms:
+            gemm_dev(f[0], f[1], 1.0, a, b, 1.0, c)
+            best = 1e30
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                gemm_dev(f[0], f[1], 1.0, a, b, 1.0, c)
+                e1.record()
+                torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1))
+            out[f"{BLAS_LETTER[dtype]}gemm_{n}_{f}_tflops"] = round(flops / best / 1e9, 2)
+        del a, b, c
+    return out
 
 
 def measured_traffic(dtype, n):
@@ -436,6 +490,7 @@ def main():
                 out["extra"].update(syrk_measurement(16384))
                 out["extra"].update(trmm_measurement(16384))
                 out["extra"].update(mixed_measurement(8192))
+                out["extra"].update(variant_measurements())
                 out["extra"]["sgemm_pct_of_peak"] = round(100 * out["extra"]["sgemm_16384_tflops"] / PEAK_TFLOPS["f32"], 2)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args)

@@ -62,6 +62,8 @@ lib.eigamd_blocked_lu_host.restype = ctypes.c_int
 lib.eigamd_blocked_lu_host.argtypes = [ctypes.c_int, _i64, _i64, _vp, _i64, _vp, _i32ptr, _i32ptr]
 lib.eigamd_getrf_dev.restype = ctypes.c_int
 lib.eigamd_getrf_dev.argtypes = [ctypes.c_int, _i64, _i64, _vp, _i64, _vp, _i64, _i32ptr, _i32ptr, _vp]
+lib.eigamd_getrf_dev_async.restype = ctypes.c_int
+lib.eigamd_getrf_dev_async.argtypes = [ctypes.c_int, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp]
 lib.eigamd_laswp_dev.restype = ctypes.c_int
 lib.eigamd_laswp_dev.argtypes = [ctypes.c_int, _vp, _i64, _i64, _vp, ctypes.c_int, ctypes.c_int, _vp]
 lib.eigamd_trsm_llnu_dev.restype = ctypes.c_int

@@ -331,6 +331,32 @@ Staging& staging() {
 
 int64_t round_up(int64_t v, int64_t q) { return (v + q - 1) / q * q; }
 
+// When a host-pointer product is dealt out over several devices (read at every call: cheap, and
+// tests change the variables between calls).
+struct MultiGpuRule {
+  int ranks = 1;
+  bool virtual_grid = false;
+  int64_t nb = 2048;
+  double min_work = 8192.0 * 8192.0 * 8192.0;
+};
+MultiGpuRule multi_gpu_rule() {
+  MultiGpuRule r;
+  if (const char* e = getenv("EIGAMD_MULTI_GPU_VIRTUAL")) {
+    r.ranks = std::max(1, atoi(e));
+    r.virtual_grid = true;
+  } else {
+    const char* off = getenv("EIGAMD_MULTI_GPU");
+    const char* world = getenv("WORLD_SIZE");
+    if ((off && atoi(off) == 0) || (world && atoi(world) > 1)) return r;
+    int count = 1;
+    if (hipGetDeviceCount(&count) != hipSuccess) count = 1;
+    r.ranks = std::min(count, 8);
+  }
+  if (const char* e = getenv("EIGAMD_MULTI_GPU_NB")) r.nb = std::max<int64_t>(16, atoll(e));
+  if (const char* e = getenv("EIGAMD_MULTI_GPU_MIN_WORK")) r.min_work = atof(e);
+  return r;
+}
+
 int gemm_host_impl(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k,
                    const double alpha[2], const void* a, int64_t lda, const void* b, int64_t ldb,
                    const double beta[2], void* c, int64_t ldc, int64_t c_inc = 1) {
@@ -339,6 +365,29 @@ int gemm_host_impl(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k,
   if (k == 0 && beta_is_one) return EIGAMD_OK;                     // level3_impl.h:62-69
   int rc = ensure_device();
   if (rc != EIGAMD_OK) return rc;
+
+  // Several GPUs visible: a large product is dealt out over all of them (eigamd_pgemm_host), as
+  // the reference splits one over the cores without the caller noticing (parallelize_gemm,
+  // Eigen/src/Core/products/Parallelizer.h:101-176).  Not when this process is one rank of a
+  // launcher that gives every GPU its own process (WORLD_SIZE > 1), and not with EIGAMD_MULTI_GPU=0.
+  // EIGAMD_MULTI_GPU_VIRTUAL=P (tests): P ranks on the current device.
+  if (c_inc == 1 && k > 0) {
+    const MultiGpuRule rule = multi_gpu_rule();
+    if (rule.ranks > 1 && (double)m * (double)n * (double)k >= rule.min_work && m >= 2 * rule.nb && n >= 2 * rule.nb) {
+      int nprow = 1;
+      for (int r = 1; r * r <= rule.ranks; ++r)
+        if (rule.ranks % r == 0) nprow = r;
+      std::vector<int> devs(rule.ranks);
+      int cur = 0;
+      (void)hipGetDevice(&cur);
+      for (int i = 0; i < rule.ranks; ++i) devs[i] = rule.virtual_grid ? cur : i;
+      double al[2] = {alpha[0], alpha[1]}, be[2] = {beta[0], beta[1]};
+      float alf[2] = {(float)alpha[0], (float)alpha[1]}, bef[2] = {(float)beta[0], (float)beta[1]};
+      const bool single = dtype == F32 || dtype == C32;
+      return eigamd_pgemm_host(dtype, opa, opb, m, n, k, single ? (const void*)alf : (const void*)al, a, lda, b, ldb,
+                               single ? (const void*)bef : (const void*)be, c, ldc, nprow, rule.ranks / nprow, rule.nb, devs.data(), 0);
+    }
+  }
 
   const int es = kElemSize[dtype];
   const int64_t a_rows = stored_rows_is_m(opa) ? m : k, a_cols = stored_rows_is_m(opa) ? k : m;
@@ -433,6 +482,23 @@ int op_of(char ch) {  // blas/common.h:47-50
 
 namespace eigamd {
 int abi_fail(int code, const std::string& what) { return fail(code, what); }  // for the other translation units of the ABI
+
+// rows x cols elements between a caller's (pageable) matrix and memory of the current device, through
+// this device's pinned chunks and copy threads; returns when the data has arrived.  (Asynchronous 2-D
+// copies straight from pageable memory, issued on several streams for neighbouring blocks of one host
+// matrix, made the runtime abort now and then; the staged form is also five times faster.)
+int staged_copy(bool to_device, void* dev, int64_t dld, void* host, int64_t ld, int64_t rows, int64_t cols, int es) {
+  Staging& st = staging();
+  std::lock_guard<std::mutex> lock(st.mu);
+  int rc = st.init();
+  if (rc != EIGAMD_OK) return rc;
+  if (to_device) {
+    if ((rc = st.upload(dev, dld, host, ld, rows, cols, es)) != EIGAMD_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(st.h2d));
+    return EIGAMD_OK;
+  }
+  return st.download(host, ld, dev, dld, rows, cols, es);
+}
 namespace {
 struct EdgeStreams {
   std::mutex mu;
@@ -473,18 +539,21 @@ hipError_t edge_streams_fork(hipStream_t s, hipStream_t* a, hipStream_t* b) {
 }
 
 namespace {
-// Buffers for the partial products of split reductions, one per (device, stream) that asked for
-// one: work queued on a stream runs in order, so one buffer per stream is never used by two
-// products at a time.  A process that multiplies on more than kSlots streams of a device gets no
-// buffer for the later ones (their products run unsplit).
+// A small pool of buffers per device for the partial products of split reductions.  Each buffer
+// remembers the stream that used it last and an event recorded behind that use.
 struct SplitWorkspaces {
   static constexpr int kSlots = 8;
   std::mutex mu;
-  int used = 0;
   int off = -1;  // -1: environment not read yet
-  hipStream_t stream[kSlots];
-  void* buf[kSlots];
-  size_t bytes[kSlots];
+  uint64_t clock = 0;
+  struct Slot {
+    hipStream_t stream = nullptr;
+    void* buf = nullptr;
+    size_t bytes = 0;
+    hipEvent_t done = nullptr;   // recorded by splitk_release
+    bool released = true, used = false;
+    uint64_t stamp = 0;
+  } slot[kSlots];
 };
 SplitWorkspaces& split_workspaces() {
   static SplitWorkspaces w[kMaxDevices];
@@ -492,7 +561,9 @@ SplitWorkspaces& split_workspaces() {
 }
 }  // namespace
 
-void* splitk_workspace(hipStream_t s, size_t bytes) {
+void* splitk_acquire(hipStream_t s, size_t bytes, int* slot_out) {
+  *slot_out = -1;
+  if (s == hipStreamPerThread) return nullptr;  // one handle value, a different stream in every host thread
   SplitWorkspaces& w = split_workspaces();
   std::lock_guard<std::mutex> lock(w.mu);
   if (w.off < 0) {
@@ -500,26 +571,51 @@ void* splitk_workspace(hipStream_t s, size_t bytes) {
     w.off = (e && atoi(e) == 0) ? 1 : 0;
   }
   if (w.off) return nullptr;
-  int i = 0;
-  while (i < w.used && w.stream[i] != s) ++i;
-  if (i == w.used) {
-    if (w.used == SplitWorkspaces::kSlots) return nullptr;
-    w.stream[i] = s; w.buf[i] = nullptr; w.bytes[i] = 0;
-    ++w.used;
+  // the buffer this stream used last; else the least recently used one that is not in the hands of
+  // a caller right now (between acquire and release)
+  int pick = -1;
+  for (int i = 0; i < SplitWorkspaces::kSlots; ++i)
+    if (w.slot[i].used && w.slot[i].stream == s && w.slot[i].released) { pick = i; break; }
+  if (pick < 0)
+    for (int i = 0; i < SplitWorkspaces::kSlots; ++i)
+      if (w.slot[i].released && (pick < 0 || w.slot[i].stamp < w.slot[pick].stamp)) pick = i;
+  if (pick < 0) return nullptr;
+  SplitWorkspaces::Slot& t = w.slot[pick];
+  // Behind the buffer's last use.  (Also when the handle is the same: a destroyed stream's handle
+  // value can come back as a new stream; on the same live stream the wait costs nothing.)
+  if (t.used && t.done && hipStreamWaitEvent(s, t.done, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
   }
-  if (w.bytes[i] < bytes) {
+  if (!t.done && hipEventCreateWithFlags(&t.done, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    t.done = nullptr;
+    return nullptr;
+  }
+  if (t.bytes < bytes) {
     // hipFree waits for the device, so nothing queued earlier still reads the old buffer.
-    if (w.buf[i]) (void)hipFree(w.buf[i]);
-    w.buf[i] = nullptr; w.bytes[i] = 0;
+    if (t.buf) (void)hipFree(t.buf);
+    t.buf = nullptr; t.bytes = 0;
     const size_t want = std::max(bytes, (size_t)32 << 20);
-    if (hipMalloc(&w.buf[i], want) != hipSuccess) {
+    if (hipMalloc(&t.buf, want) != hipSuccess) {
       (void)hipGetLastError();
-      w.buf[i] = nullptr;
+      t.buf = nullptr;
       return nullptr;
     }
-    w.bytes[i] = want;
+    t.bytes = want;
   }
-  return w.buf[i];
+  t.stream = s; t.used = true; t.released = false; t.stamp = ++w.clock;
+  *slot_out = pick;
+  return t.buf;
+}
+
+void splitk_release(int slot, hipStream_t s) {
+  SplitWorkspaces& w = split_workspaces();
+  std::lock_guard<std::mutex> lock(w.mu);
+  if (slot < 0 || slot >= SplitWorkspaces::kSlots) return;
+  SplitWorkspaces::Slot& t = w.slot[slot];
+  if (t.done) (void)hipEventRecord(t.done, s);
+  t.released = true;
 }
 
 hipError_t edge_streams_join(hipStream_t s, hipStream_t a, hipStream_t b) {
@@ -828,6 +924,18 @@ int eigamd_getrf_dev(int dtype, int64_t m, int64_t n, void* d_a, int64_t lda, in
   }
   if (first_zero_pivot) *first_zero_pivot = fz;
   if (nb_transpositions) *nb_transpositions = nb;
+  return EIGAMD_OK;
+}
+
+int eigamd_getrf_dev_async(int dtype, int64_t m, int64_t n, void* d_a, int64_t lda, int* d_transp, int64_t max_block_size,
+                           int* d_info, void* stream) {
+  if (dtype != F32 && dtype != F64) return fail(EIGAMD_ERR_ARG, "LU supports the real kinds (f32, f64)");
+  if (m < 1 || n < 1 || lda < m || m > 0x7fffffff || n > 0x7fffffff || !d_info)
+    return fail(EIGAMD_ERR_ARG, "invalid LU arguments");
+  int rc = ensure_device();
+  if (rc != EIGAMD_OK) return rc;
+  int fz = -1, nb = 0;
+  HIP_TRY(getrf_device(dtype, m, n, d_a, lda, d_transp, max_block_size, &fz, &nb, static_cast<hipStream_t>(stream), true, d_info));
   return EIGAMD_OK;
 }
 

@@ -77,10 +77,15 @@ hipError_t edge_streams_fork(hipStream_t s, hipStream_t* a, hipStream_t* b);
 hipError_t edge_streams_join(hipStream_t s, hipStream_t a, hipStream_t b);
 
 // Device memory for the partial products of a reduction split over several workgroups per tile
-// (launch_whole): at least `bytes`, owned by the library, private to stream `s` of the current
-// device.  nullptr: none to be had (switched off by EIGAMD_SPLITK=0, too many streams, out of
-// memory); the product then runs unsplit.  Defined in blas_abi.hip.
-void* splitk_workspace(hipStream_t s, size_t bytes);
+// (launch_whole): at least `bytes`, owned by the library, one of a small pool per device.  A buffer
+// goes to the stream that used it last when there is one (work queued on a stream runs in order);
+// otherwise the least recently used buffer is taken and `s` is made to wait for its last user.
+// *slot identifies the buffer for splitk_release, which the caller invokes once the work that reads
+// the buffer has been queued on `s`.  nullptr: none to be had (switched off by EIGAMD_SPLITK=0,
+// hipStreamPerThread -- one handle, a different stream in every host thread --, out of memory); the
+// product then runs unsplit.  Defined in blas_abi.hip.
+void* splitk_acquire(hipStream_t s, size_t bytes, int* slot);
+void splitk_release(int slot, hipStream_t s);
 
 hipError_t launch_gemm_f32(const GemmCall&, hipStream_t);
 hipError_t launch_gemm_f64(const GemmCall&, hipStream_t);
@@ -247,10 +252,12 @@ static hipError_t launch_whole(const GemmCall& c, hipStream_t stream) {
   const int splits = choose_splits<KIND>(c, &k_chunk);
   if (splits > 1) {
     const size_t bytes = (size_t)splits * c.m * c.n * G::ES;
-    if (void* partials = c.partials ? (bytes <= c.partials_bytes ? c.partials : nullptr) : splitk_workspace(stream, bytes)) {
+    int slot = -1;
+    if (void* partials = c.partials ? (bytes <= c.partials_bytes ? c.partials : nullptr) : splitk_acquire(stream, bytes, &slot)) {
       hipError_t e = launch_region<KIND, AK, BKC, GUARD>(c, 0, 0, c.m, c.n, stream, splits, k_chunk, partials);
-      if (e != hipSuccess) return e;
-      return reduce_partials<KIND>(c, 0, 0, c.m, c.n, splits, partials, stream);
+      if (e == hipSuccess) e = reduce_partials<KIND>(c, 0, 0, c.m, c.n, splits, partials, stream);
+      if (slot >= 0) splitk_release(slot, stream);
+      return e;
     }
     return launch_region<KIND, AK, BKC, GUARD>(c, 0, 0, c.m, c.n, stream);
   }
@@ -259,16 +266,17 @@ static hipError_t launch_whole(const GemmCall& c, hipStream_t stream) {
     const int64_t r0 = t.by_rows ? t.cut : 0, c0 = t.by_rows ? 0 : t.cut;
     const int64_t rows = c.m - r0, cols = c.n - c0;
     const size_t bytes = (size_t)t.splits * rows * cols * G::ES;
+    int slot = -1;
     void* partials = t.splits <= 1 ? nullptr
                      : c.partials  ? (bytes <= c.partials_bytes ? c.partials : nullptr)
-                                   : splitk_workspace(stream, bytes);
+                                   : splitk_acquire(stream, bytes, &slot);
     if (t.splits == 1 || partials) {
       hipError_t e = launch_region<KIND, AK, BKC, GUARD>(c, 0, 0, t.by_rows ? t.cut : c.m, t.by_rows ? c.n : t.cut, stream);
-      if (e != hipSuccess) return e;
-      if (t.splits == 1) return launch_region<KIND, AK, BKC, GUARD>(c, r0, c0, rows, cols, stream);
-      e = launch_region<KIND, AK, BKC, GUARD>(c, r0, c0, rows, cols, stream, t.splits, t.k_chunk, partials);
-      if (e != hipSuccess) return e;
-      return reduce_partials<KIND>(c, r0, c0, rows, cols, t.splits, partials, stream);
+      if (e == hipSuccess && t.splits == 1) return launch_region<KIND, AK, BKC, GUARD>(c, r0, c0, rows, cols, stream);
+      if (e == hipSuccess) e = launch_region<KIND, AK, BKC, GUARD>(c, r0, c0, rows, cols, stream, t.splits, t.k_chunk, partials);
+      if (e == hipSuccess) e = reduce_partials<KIND>(c, r0, c0, rows, cols, t.splits, partials, stream);
+      if (slot >= 0) splitk_release(slot, stream);
+      return e;
     }
   }
   return launch_region<KIND, AK, BKC, GUARD>(c, 0, 0, c.m, c.n, stream);

@@ -676,6 +676,14 @@ __global__ void lu_rowops(T* __restrict__ A_left, int nleft, T* __restrict__ A_r
     if (i < jb) col[k0 + i] = x[i];
 }
 
+// info[0] = first zero pivot or -1, info[1] = number of exchanges, info[2] = 1 when a workgroup of the
+// one-launch base case gave up waiting: the counters of a factorisation, for callers that do not wait.
+__global__ void lu_export_info(const int* __restrict__ header, int* __restrict__ info) {
+  info[0] = header[0];
+  info[1] = header[1];
+  info[2] = header[4];
+}
+
 // transp[i] = i: every entry is a valid (identity) transposition before the factorisation
 // fills it in, whatever happens to the kernels in between.
 __global__ void lu_iota(int* __restrict__ transp, int n) {
@@ -1641,7 +1649,7 @@ hipError_t make_streams(LuStreams& st, int base_workgroups, int per_cu, int* tot
 
 template <typename T>
 hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp, int64_t max_block,
-                          int* first_zero_pivot, int* nb_transpositions, hipStream_t s, bool allow_fused) {
+                          int* first_zero_pivot, int* nb_transpositions, hipStream_t s, bool allow_fused, int* d_info) {
   LuScratch& sc = scratch();
   std::lock_guard<std::mutex> lock(sc.mu);
   const size_t nparts = (size_t)((m + kRowsPerBlock - 1) / kRowsPerBlock) + 1;
@@ -1725,6 +1733,10 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   } else {  // a panel: nothing to overlap with
     LU_TRY(blocked<T>(A, ld, 0, 0, m, n, d_transp, max_block, w, s));
   }
+  if (d_info) {  // the caller reads the counters from device memory, behind `s`: nothing to wait for
+    hipLaunchKernelGGL(lu_export_info, dim3(1), dim3(1), 0, s, w.first_zero, d_info);
+    return hipGetLastError();
+  }
   int out[5] = {-1, 0, 0, 0, 0};
   LU_TRY(hipMemcpyAsync(out, w.first_zero, sizeof out, hipMemcpyDeviceToHost, s));
   LU_TRY(hipStreamSynchronize(s));
@@ -1740,14 +1752,14 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
 }  // namespace
 
 hipError_t getrf_device(int kind, int64_t m, int64_t n, void* A, int64_t ld, int* d_transp, int64_t max_block,
-                        int* first_zero_pivot, int* nb_transpositions, hipStream_t s, bool allow_fused) {
+                        int* first_zero_pivot, int* nb_transpositions, hipStream_t s, bool allow_fused, int* d_info) {
   if (max_block < 8) max_block = 8;
   if (kind == F64)
     return getrf_device_t<double>(m, n, static_cast<double*>(A), ld, d_transp, max_block, first_zero_pivot,
-                                  nb_transpositions, s, allow_fused);
+                                  nb_transpositions, s, allow_fused, d_info);
   if (kind == F32)
     return getrf_device_t<float>(m, n, static_cast<float*>(A), ld, d_transp, max_block, first_zero_pivot,
-                                 nb_transpositions, s, allow_fused);
+                                 nb_transpositions, s, allow_fused, d_info);
   return hipErrorInvalidValue;
 }
 

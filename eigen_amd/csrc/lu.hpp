@@ -18,7 +18,10 @@ namespace eigamd {
 // only grid-wide synchronisation is the kernel boundary).
 constexpr hipError_t kLuNotResident = hipErrorNotReady;
 hipError_t getrf_device(int kind, int64_t m, int64_t n, void* A, int64_t ld, int* d_transp, int64_t max_block,
-                        int* first_zero_pivot, int* nb_transpositions, hipStream_t s, bool allow_fused = true);
+                        int* first_zero_pivot, int* nb_transpositions, hipStream_t s, bool allow_fused = true,
+                        int* d_info = nullptr);
+// With d_info (device memory, 3 ints) the call does not wait: behind `s`, d_info holds the first zero
+// pivot or -1, the number of exchanges, and 1 where the call without it would return kLuNotResident.
 
 // Row transpositions i <-> d_transp[i], i in [k0, k1), on ncols columns starting at A
 // (row indices are rows of A).

@@ -38,6 +38,7 @@
 
 namespace eigamd {
 int abi_fail(int code, const std::string& what);  // blas_abi.hip: sets eigamd_last_error()
+int staged_copy(bool to_device, void* dev, int64_t dld, void* host, int64_t ld, int64_t rows, int64_t cols, int es);
 }
 using namespace eigamd;
 
@@ -341,8 +342,9 @@ int issue_products(eigamd_pgemm& g, int64_t p, const double alpha[2], const doub
   return EIGAMD_OK;
 }
 
-// Host <-> local parts: one 2-D copy per nb x nb block (block (bi, bj) of the stored matrix lives
-// on the rank whose grid coordinates are the block indices modulo the grid extents).
+// Host <-> local parts, block by block through the owning device's pinned staging (block (bi, bj) of
+// the stored matrix lives on the rank whose grid coordinates are the block indices modulo the grid
+// extents).  Synchronous; the local parts must be at rest (eigamd_pgemm_sync) before a gather.
 int move_blocks(eigamd_pgemm& g, int which, char* host, int64_t ld, bool to_device) {
   // stored extents and which grid dimension deals out the stored rows / columns
   int64_t rows, cols;
@@ -361,17 +363,9 @@ int move_blocks(eigamd_pgemm& g, int which, char* host, int64_t ld, bool to_devi
       char* dev = static_cast<char*>(l.ptr) + (size_t)((bi / np_r) * g.nb + (bj / np_c) * g.nb * l.ld) * g.es;
       char* hst = host + (size_t)(bi * g.nb + bj * g.nb * ld) * g.es;
       DeviceGuard dg(r.dev);
-      if (to_device)
-        PG_HIP(hipMemcpy2DAsync(dev, (size_t)l.ld * g.es, hst, (size_t)ld * g.es, (size_t)nr * g.es, (size_t)nc, hipMemcpyHostToDevice, r.compute));
-      else
-        PG_HIP(hipMemcpy2DAsync(hst, (size_t)ld * g.es, dev, (size_t)l.ld * g.es, (size_t)nr * g.es, (size_t)nc, hipMemcpyDeviceToHost, r.compute));
+      PG_TRY(staged_copy(to_device, dev, l.ld, hst, ld, nr, nc, g.es));
     }
   }
-  if (!to_device)
-    for (Rank& r : g.ranks) {
-      DeviceGuard dg(r.dev);
-      PG_HIP(hipStreamSynchronize(r.compute));
-    }
   return EIGAMD_OK;
 }
 
@@ -475,11 +469,13 @@ int eigamd_pgemm_fill(eigamd_pgemm* g, int which, uint64_t seed) {
 
 int eigamd_pgemm_scatter(eigamd_pgemm* g, int which, const void* host, int64_t ld) {
   if (!g || which < 0 || which > 2 || !host) return abi_fail(EIGAMD_ERR_ARG, "invalid pgemm_scatter arguments");
+  PG_TRY(eigamd_pgemm_sync(g));
   return move_blocks(*g, which, const_cast<char*>(static_cast<const char*>(host)), ld, true);
 }
 
 int eigamd_pgemm_gather(eigamd_pgemm* g, int which, void* host, int64_t ld) {
   if (!g || which < 0 || which > 2 || !host) return abi_fail(EIGAMD_ERR_ARG, "invalid pgemm_gather arguments");
+  PG_TRY(eigamd_pgemm_sync(g));
   return move_blocks(*g, which, static_cast<char*>(host), ld, false);
 }
 

@@ -56,6 +56,17 @@ def getrf_dev(a, stream=None, max_block_size=256, transp=None):
     return transp[:size], nb.value, fz.value
 
 
+def getrf_dev_async(a, transp, info, stream=None, max_block_size=256):
+    """In-place LU of a DeviceMatrix without waiting for it: `transp` (int32 device tensor,
+    min(rows, cols) entries) receives the transpositions and `info` (int32 device tensor, 3
+    entries) the first zero pivot or -1, the number of exchanges and a status, all behind the
+    stream."""
+    from .device import _stream_ptr
+    rc = lib.eigamd_getrf_dev_async(a.kind, a.rows, a.cols, ctypes.c_void_p(a.ptr), a.ld, ctypes.c_void_p(transp.data_ptr()),
+                                    max_block_size, ctypes.c_void_p(info.data_ptr()), _stream_ptr(stream))
+    _lib.check(rc, "eigamd_getrf_dev_async")
+
+
 def laswp_dev(a, transp, k0, k1, stream=None):
     """Exchange rows i and transp[i] of the DeviceMatrix `a`, i = k0 .. k1-1 in order
     (transp: int32 device tensor of row indices of `a`)."""

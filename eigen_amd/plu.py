@@ -59,13 +59,15 @@ class ColCyclicMatrix:
 
 
 class DeviceOps:
-    """The four local steps on the library's device entry points."""
+    """The four local steps on the library's device entry points.  None of them waits for the
+    device: the panel's counters stay in device memory."""
 
     @staticmethod
     def panel_lu(panel, transp):
-        from .lu import getrf_dev
-        _, nswaps, first_zero = getrf_dev(panel, max_block_size=16, transp=transp)
-        return first_zero, nswaps
+        from .lu import getrf_dev_async
+        info = torch.empty(3, dtype=torch.int32, device=transp.device)
+        getrf_dev_async(panel, transp, info, max_block_size=16)
+        return info[0], info[1]
 
     @staticmethod
     def laswp(a, transp, k0, k1):
@@ -85,7 +87,14 @@ class DeviceOps:
 
 def pgetrf(A, ops=DeviceOps, broadcast=None):
     """In-place P*A = L*U of a ColCyclicMatrix.  Returns (transpositions: int32 tensor of
-    n global row indices on A's device, nb_transpositions, first_zero_pivot)."""
+    n global row indices on A's device, nb_transpositions, first_zero_pivot).
+
+    One panel of look-ahead: as soon as panel j has arrived, the owner of column block j+1
+    brings that block up to date, factorises it and starts its broadcast; only then does every
+    rank update the rest of its columns with panel j, so panel j+1 is already there (or on its
+    way) when that update ends.  Panels alternate between two receive buffers.  The host never
+    waits for the device inside the loop: the zero-pivot and exchange counters are kept in
+    device memory and read once at the end."""
     if broadcast is None:
         broadcast = device_broadcast
     n, nb, P, r = A.n, A.nb, A.world, A.rank
@@ -94,47 +103,68 @@ def pgetrf(A, ops=DeviceOps, broadcast=None):
     dev = A.local.storage.device
     tdt = _TORCH_OF_KIND[A.kind]
     transp = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
-    pbuf = torch.empty(max(n * nb, 1), dtype=tdt, device=dev)     # the factorised panel, contiguous
-    meta = torch.zeros(nb + 2, dtype=torch.int32, device=dev)     # transpositions of the panel, first_zero, nswaps
-    first_zero, nswaps = -1, 0
+    pbuf = [torch.empty(max(n * nb, 1), dtype=tdt, device=dev) for _ in range(2)]   # factorised panels, contiguous
+    meta = [torch.zeros(nb + 2, dtype=torch.int32, device=dev) for _ in range(2)]  # transpositions, first_zero, nswaps
+    first_zero = torch.full((), -1, dtype=torch.int32, device=dev)
+    nswaps = torch.zeros((), dtype=torch.int32, device=dev)
     nblocks = (n + nb - 1) // nb
-    for j in range(nblocks):
-        k = j * nb
-        bs = min(nb, n - k)
-        rows_p = n - k
-        owner = j % P
-        panel = DeviceMatrix(rows_p, bs, A.kind, ld=max(rows_p, 1), storage=pbuf)
+
+    def extent(j):
+        return j * nb, min(nb, n - j * nb)
+
+    def factor_and_send(j):
+        """Panel j: factorised by its owner (its columns are up to date), then on its way to everybody."""
+        k, bs = extent(j)
+        s, owner, rows_p = j & 1, j % P, n - k
         if r == owner:
-            loc = (j // P) * nb
-            mine = A.local.block(k, loc, rows_p, bs)
-            fz, ns = ops.panel_lu(mine, meta[:bs])          # transpositions relative to row k
-            panel.as_strided().copy_(mine.as_strided())
-            meta[:bs] += k
-            meta[nb] = fz
-            meta[nb + 1] = ns
+            mine = A.local.block(k, (j // P) * nb, rows_p, bs)
+            fz, ns = ops.panel_lu(mine, meta[s][:bs])           # transpositions relative to row k
+            DeviceMatrix(rows_p, bs, A.kind, ld=max(rows_p, 1), storage=pbuf[s]).as_strided().copy_(mine.as_strided())
+            meta[s][:bs] += k
+            meta[s][nb] = torch.as_tensor(fz, dtype=torch.int32)
+            meta[s][nb + 1] = torch.as_tensor(ns, dtype=torch.int32)
         if P > 1:
-            works = [broadcast(pbuf[:rows_p * bs], owner), broadcast(meta, owner)]
-            for w in works:
-                w.wait()
-        fz, ns = int(meta[nb].item()), int(meta[nb + 1].item())
-        if fz >= 0 and first_zero == -1:
-            first_zero = k + fz
-        nswaps += ns
-        transp[k:k + bs] = meta[:bs]
-        # columns this rank owns left / right of the panel
+            return [broadcast(pbuf[s][:rows_p * bs], owner), broadcast(meta[s], owner)]
+        return []
+
+    def apply(j, c0, c1):
+        """Transpositions, triangular solve and trailing update of panel j on the local columns [c0, c1)."""
+        k, bs = extent(j)
+        trows = n - k - bs
+        if c1 <= c0:
+            return
+        cols = A.local.block(0, c0, n, c1 - c0)
+        ops.laswp(cols, transp, k, k + bs)
+        if trows > 0:
+            panel = DeviceMatrix(n - k, bs, A.kind, ld=max(n - k, 1), storage=pbuf[j & 1])
+            a12 = A.local.block(k, c0, bs, c1 - c0)
+            ops.trsm(panel.block(0, 0, bs, bs), a12)
+            ops.gemm_minus(panel.block(bs, 0, trows, bs), a12, A.local.block(k + bs, c0, trows, c1 - c0))
+
+    works = factor_and_send(0) if nblocks else []
+    for j in range(nblocks):
+        k, bs = extent(j)
+        s, owner = j & 1, j % P
+        for w in works:
+            w.wait()
+        fz = meta[s][nb]
+        first_zero = torch.where((first_zero < 0) & (fz >= 0), fz + k, first_zero)
+        nswaps = nswaps + meta[s][nb + 1]
+        transp[k:k + bs] = meta[s][:bs]
+        # local columns left of / right of the panel
         owned_upto_j = (j - r) // P + 1 if r <= j else 0          # local blocks with global index <= j
         c_right = min(owned_upto_j * nb, A.nloc)
-        if r == owner:
-            c_left_end = (j // P) * nb
-        else:
-            c_left_end = c_right
+        c_left_end = (j // P) * nb if r == owner else c_right
+        done_upto = c_right                                         # right-hand columns already updated with panel j
+        if j + 1 < nblocks:
+            if r == (j + 1) % P:                                    # look-ahead: the next panel's columns first
+                loc1 = ((j + 1) // P) * nb
+                apply(j, loc1, loc1 + extent(j + 1)[1])
+                assert loc1 == c_right
+                done_upto = loc1 + extent(j + 1)[1]
+            works = factor_and_send(j + 1)
         if c_left_end > 0:
             ops.laswp(A.local.block(0, 0, n, c_left_end), transp, k, k + bs)
-        ncr = A.nloc - c_right
-        trows = n - k - bs
-        if ncr > 0 and trows > 0:
-            ops.laswp(A.local.block(0, c_right, n, ncr), transp, k, k + bs)
-            a12 = A.local.block(k, c_right, bs, ncr)
-            ops.trsm(panel.block(0, 0, bs, bs), a12)
-            ops.gemm_minus(panel.block(bs, 0, trows, bs), a12, A.local.block(k + bs, c_right, trows, ncr))
-    return transp[:n], nswaps, first_zero
+        apply(j, done_upto, A.nloc)
+    fz_host, ns_host = int(first_zero), int(nswaps)                 # the only wait for the device
+    return transp[:n], ns_host, fz_host

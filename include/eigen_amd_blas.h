@@ -180,6 +180,12 @@ int dgetrf_(const int* m, const int* n, double* a, const int* lda, int* ipiv, in
 int sgetrf_(const int* m, const int* n, float* a, const int* lda, int* ipiv, int* info);
 int eigamd_getrf_dev(int dtype, int64_t m, int64_t n, void* d_a, int64_t lda, int* d_transp,
                      int64_t max_block_size, int* first_zero_pivot, int* nb_transpositions, void* stream);
+/* The same without waiting (m, n >= 1): behind `stream`, the 3 ints at d_info (device memory) hold the first
+ * zero pivot or -1, the number of row exchanges, and a status (0, or 1 where eigamd_getrf_dev would have
+ * returned EIGAMD_ERR_DEVICE because the panel kernel's workgroups were not resident together).  For
+ * drivers that keep the whole factorisation on the device (the multi-GPU LU). */
+int eigamd_getrf_dev_async(int dtype, int64_t m, int64_t n, void* d_a, int64_t lda, int* d_transp, int64_t max_block_size,
+                           int* d_info, void* stream);
 
 /* The two other steps of one blocked_lu iteration, on device memory, for drivers that
  * own the loop themselves (the multi-GPU LU): the row transpositions of

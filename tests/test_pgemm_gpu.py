@@ -103,3 +103,13 @@ def test_arguments():
         pgemm_host("N", "N", 1.0, a, a, 0.0, a.copy(order="F"), 1, 2, 2, devices=[0, 0], transport=RCCL)   # RCCL: one device per rank
     with pytest.raises(_lib.EigenAmdError):
         pgemm_host("N", "N", 1.0, a, a, 0.0, a.copy(order="F"), 1, 2, 2, devices=[0, 99])
+
+
+def test_host_entry_deals_a_large_product_over_the_grid():
+    """?gemm_ itself goes through the grid when several devices are visible and the product is
+    large; here four ranks on the one device stand in for four devices."""
+    from test_lu_config_gpu import env
+    from test_gemm_config_gpu import host_product_sampled
+    with env(EIGAMD_MULTI_GPU_VIRTUAL=4, EIGAMD_MULTI_GPU_NB=512, EIGAMD_MULTI_GPU_MIN_WORK=1e9):
+        host_product_sampled(1, "N", "N", 4096, 4200, 3000, 1.0, 1.0, pad=8)
+        host_product_sampled(3, "C", "N", 2048, 2100, 1500, 0.7 - 0.9j, 1.3 - 1.1j, pad=3)
