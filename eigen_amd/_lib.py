@@ -60,6 +60,8 @@ lib.eigamd_fill_uniform_host.argtypes = [ctypes.c_int, _vp, _i64, _i64, _i64, ct
 _i32ptr = ctypes.POINTER(ctypes.c_int)
 lib.eigamd_blocked_lu_host.restype = ctypes.c_int
 lib.eigamd_blocked_lu_host.argtypes = [ctypes.c_int, _i64, _i64, _vp, _i64, _vp, _i32ptr, _i32ptr]
+lib.eigamd_blocked_lu_host_rowmajor.restype = ctypes.c_int
+lib.eigamd_blocked_lu_host_rowmajor.argtypes = lib.eigamd_blocked_lu_host.argtypes
 lib.eigamd_getrf_dev.restype = ctypes.c_int
 lib.eigamd_getrf_dev.argtypes = [ctypes.c_int, _i64, _i64, _vp, _i64, _vp, _i64, _i32ptr, _i32ptr, _vp]
 lib.eigamd_getrf_dev_async.restype = ctypes.c_int

@@ -357,6 +357,63 @@ MultiGpuRule multi_gpu_rule() {
   return r;
 }
 
+// Small products (every operand fits a fraction of one pinned chunk): the general path below wakes the
+// copy threads, issues a 2-D copy per operand on three streams and waits on events -- 130 us before any
+// work is done.  Here the calling thread packs A, B and (unless beta == 0) C into one pinned chunk, ONE
+// copy takes them up, the kernel runs, ONE copy brings C back, one wait.  There is still no CPU product:
+// a 32^3 dgemm_ costs about 50 us where Eigen's own kernel needs 1 us (no fallback, by design).
+constexpr size_t kSmallProductBytes = (size_t)3 << 20;
+int gemm_host_small(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k, const double alpha[2], const void* a,
+                    int64_t lda, const void* b, int64_t ldb, const double beta[2], void* c, int64_t ldc) {
+  const int es = kElemSize[dtype];
+  const int64_t a_rows = stored_rows_is_m(opa) ? m : k, a_cols = stored_rows_is_m(opa) ? k : m;
+  const int64_t b_rows = stored_rows_is_m(opb) ? k : n, b_cols = stored_rows_is_m(opb) ? n : k;
+  const int64_t dlda = round_up(std::max<int64_t>(a_rows, 1), 16), dldb = round_up(std::max<int64_t>(b_rows, 1), 16);
+  const int64_t dldc = round_up(m, 16);
+  const bool beta_is_zero = beta[0] == 0.0 && beta[1] == 0.0;
+  const size_t a_bytes = k > 0 ? (size_t)dlda * a_cols * es : 0, b_bytes = k > 0 ? (size_t)dldb * b_cols * es : 0;
+  const size_t c_bytes = (size_t)dldc * n * es;
+  const size_t off_b = round_up((int64_t)a_bytes, 256), off_c = off_b + round_up((int64_t)b_bytes, 256);
+  const size_t up_bytes = beta_is_zero ? off_c : off_c + c_bytes;
+
+  Staging& st = staging();
+  std::lock_guard<std::mutex> lock(st.mu);
+  int rc = st.init();
+  if (rc != EIGAMD_OK) return rc;
+  if ((rc = st.reserve(0, off_c + c_bytes)) != EIGAMD_OK) return rc;
+  HIP_TRY(hipEventSynchronize(st.up_free[0]));  // (a large product's last upload out of this chunk)
+  char* pin = static_cast<char*>(st.up[0]);
+  auto pack = [&](char* dst, int64_t dld, const void* src, int64_t ld, int64_t rows, int64_t cols) {
+    const char* sp = static_cast<const char*>(src);
+    if (ld == dld && cols > 0) { std::memcpy(dst, sp, ((size_t)ld * (cols - 1) + rows) * es); return; }  // (the last column ends after `rows`)
+    for (int64_t j = 0; j < cols; ++j) std::memcpy(dst + (size_t)j * dld * es, sp + (size_t)j * ld * es, (size_t)rows * es);
+  };
+  if (k > 0) {
+    pack(pin, dlda, a, lda, a_rows, a_cols);
+    pack(pin + off_b, dldb, b, ldb, b_rows, b_cols);
+  }
+  if (!beta_is_zero) pack(pin + off_c, dldc, c, ldc, m, n);
+  char* dev = static_cast<char*>(st.buf[0]);
+  if (up_bytes > 0) HIP_TRY(hipMemcpyAsync(dev, pin, up_bytes, hipMemcpyHostToDevice, st.stream));
+  GemmCall call;
+  call.kind = dtype; call.opa = opa; call.opb = opb;
+  call.m = m; call.n = n; call.k = k;
+  call.alpha[0] = alpha[0]; call.alpha[1] = alpha[1];
+  call.beta[0] = beta[0]; call.beta[1] = beta[1];
+  call.A = dev; call.lda = dlda;
+  call.B = dev + off_b; call.ldb = dldb;
+  call.C = dev + off_c; call.ldc = dldc;
+  call.serial_edges = true;  // (a product this small is one launch anyway; no helper streams)
+  HIP_TRY(launch(call, st.stream));
+  char* back = static_cast<char*>(st.down[0]);
+  HIP_TRY(hipMemcpyAsync(back, dev + off_c, c_bytes, hipMemcpyDeviceToHost, st.stream));
+  HIP_TRY(hipStreamSynchronize(st.stream));
+  // only the m x n window goes back: rows m..ldc-1 of C keep the caller's bytes
+  char* cp = static_cast<char*>(c);
+  for (int64_t j = 0; j < n; ++j) std::memcpy(cp + (size_t)j * ldc * es, back + (size_t)j * dldc * es, (size_t)m * es);
+  return EIGAMD_OK;
+}
+
 int gemm_host_impl(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k,
                    const double alpha[2], const void* a, int64_t lda, const void* b, int64_t ldb,
                    const double beta[2], void* c, int64_t ldc, int64_t c_inc = 1) {
@@ -391,6 +448,12 @@ int gemm_host_impl(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k,
 
   const int es = kElemSize[dtype];
   const int64_t a_rows = stored_rows_is_m(opa) ? m : k, a_cols = stored_rows_is_m(opa) ? k : m;
+  {
+    const int64_t b_rows = stored_rows_is_m(opb) ? k : n, b_cols = stored_rows_is_m(opb) ? n : k;
+    const size_t total = ((size_t)round_up(a_rows, 16) * a_cols + (size_t)round_up(b_rows, 16) * b_cols + (size_t)round_up(m, 16) * n) * es;
+    if (c_inc == 1 && total <= kSmallProductBytes)
+      return gemm_host_small(dtype, opa, opb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc);
+  }
   // The device images are this library's own, so their m and n extents are rounded up to whole
   // tiles and the kernel is launched on the rounded extents: every workgroup then runs the
   // vector-load instantiation and no bounds-checked edge launch is needed.  What the padding
@@ -965,8 +1028,11 @@ int eigamd_trsm_llnu_dev(int dtype, int64_t m, int64_t n, const void* d_l, int64
 // Host-pointer LU: stage in, factorise on the device, copy factors and
 // transpositions back.  Returns the index of the first zero pivot or -1 through
 // *first_zero_pivot, like partial_lu_impl::blocked_lu (PartialPivLU.h:429).
+// `inc`: distance between consecutive rows of a column (1 for a column-major matrix; a row-major matrix
+// with row stride s is the case lda = 1, inc = s: the copy threads gather it into the dense column-major
+// device image and scatter the factors back).
 static int lu_host_impl(int dtype, int64_t m, int64_t n, void* a, int64_t lda, int* transp, int* first_zero_pivot,
-                        int* nb_transpositions) {
+                        int* nb_transpositions, int64_t inc = 1) {
   *first_zero_pivot = -1;
   *nb_transpositions = 0;
   if (m == 0 || n == 0) return EIGAMD_OK;
@@ -984,7 +1050,7 @@ static int lu_host_impl(int dtype, int64_t m, int64_t n, void* a, int64_t lda, i
   // base case cannot run (its workgroups were not all resident, the device being shared with
   // other work), the copy is made afresh and factorised through the per-column kernels.
   for (int attempt = 0; attempt < 2; ++attempt) {
-    if ((rc = st.upload(st.buf[2], dld, a, lda, m, n, es)) != EIGAMD_OK) return rc;
+    if ((rc = st.upload(st.buf[2], dld, a, lda, m, n, es, inc)) != EIGAMD_OK) return rc;
     HIP_TRY(hipEventRecord(st.uploaded, st.h2d));
     HIP_TRY(hipStreamWaitEvent(st.stream, st.uploaded, 0));
     const hipError_t e = getrf_device(dtype, m, n, st.buf[2], dld, static_cast<int*>(st.buf[0]), 256, first_zero_pivot,
@@ -995,7 +1061,7 @@ static int lu_host_impl(int dtype, int64_t m, int64_t n, void* a, int64_t lda, i
   }
   HIP_TRY(hipMemcpyAsync(transp, st.buf[0], (size_t)size * sizeof(int), hipMemcpyDeviceToHost, st.stream));
   HIP_TRY(hipStreamSynchronize(st.stream));   // getrf_device has synchronised already; this covers the copy
-  if ((rc = st.download(a, lda, st.buf[2], dld, m, n, es)) != EIGAMD_OK) return rc;
+  if ((rc = st.download(a, lda, st.buf[2], dld, m, n, es, inc)) != EIGAMD_OK) return rc;
   return EIGAMD_OK;
 }
 
@@ -1005,6 +1071,14 @@ int eigamd_blocked_lu_host(int dtype, int64_t rows, int64_t cols, void* lu, int6
   if (rows < 0 || cols < 0 || lu_stride < std::max<int64_t>(1, rows) || rows > 0x7fffffff || cols > 0x7fffffff)
     return fail(EIGAMD_ERR_ARG, "invalid LU arguments");
   return lu_host_impl(dtype, rows, cols, lu, lu_stride, row_transpositions, first_zero_pivot, nb_transpositions);
+}
+
+int eigamd_blocked_lu_host_rowmajor(int dtype, int64_t rows, int64_t cols, void* lu, int64_t lu_stride, int* row_transpositions,
+                                    int* nb_transpositions, int* first_zero_pivot) {
+  if (dtype != F32 && dtype != F64) return fail(EIGAMD_ERR_ARG, "LU supports the real kinds (f32, f64)");
+  if (rows < 0 || cols < 0 || lu_stride < std::max<int64_t>(1, cols) || rows > 0x7fffffff || cols > 0x7fffffff)
+    return fail(EIGAMD_ERR_ARG, "invalid LU arguments");
+  return lu_host_impl(dtype, rows, cols, lu, /*lda=*/1, row_transpositions, first_zero_pivot, nb_transpositions, /*inc=*/lu_stride);
 }
 
 static int f77_getrf(int dtype, const char* name, const int* m, const int* n, void* a, const int* lda, int* ipiv,

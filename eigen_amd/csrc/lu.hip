@@ -1592,6 +1592,32 @@ LuScratch& scratch() {
   return s[current_device_slot()];
 }
 
+void release_lu_streams() {
+  int count = 0, prev = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) return;
+  (void)hipGetDevice(&prev);
+  for (int d = 0; d < count && d < kMaxDevices; ++d) {
+    if (hipSetDevice(d) != hipSuccess) continue;
+    LuScratch& sc = scratch();
+    std::lock_guard<std::mutex> lock(sc.mu);
+    LuStreams& st = sc.streams;
+    for (hipStream_t* q : {&st.panel, &st.update})
+      if (*q) {
+        (void)hipStreamSynchronize(*q);
+        (void)hipStreamDestroy(*q);
+        *q = nullptr;
+      }
+    for (hipEvent_t* e : {&st.ready, &st.factored, &st.fork, &st.join})
+      if (*e) {
+        (void)hipEventDestroy(*e);
+        *e = nullptr;
+      }
+    st.panel_cus = 0;
+  }
+  (void)hipSetDevice(prev);
+  (void)hipGetLastError();
+}
+
 // Streams of the look-ahead.  When the chip has CUs to spare (EIGAMD_LU_PANEL_CUS, default
 // 32 of 256; 0 switches this off) the panel stream owns `panel_cus` compute units and the
 // update stream the others, so the many short kernels of a panel never queue behind the
@@ -1643,6 +1669,12 @@ hipError_t make_streams(LuStreams& st, int base_workgroups, int per_cu, int* tot
 
   }
   st.panel_cus = want;
+  // The streams with a compute-unit mask are given back before the process's libraries shut down.  (Left to
+  // the end they outlive the runtime objects a profiler keeps about them: under `rocprofv3 --kernel-trace` a
+  // Python process that had factorised anything ended in a fault inside the profiler's finaliser; processes
+  // that only multiplied or solved, which never create such a stream, did not.)
+  static const int registered = std::atexit(release_lu_streams);
+  (void)registered;
   if (getenv("EIGAMD_LU_DEBUG")) fprintf(stderr, "eigen_amd LU: panel CUs %d of %d, base-case workgroups %d, %d per CU\n", want, total, base_workgroups, per_cu);
   return hipSuccess;
 }

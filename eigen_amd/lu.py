@@ -27,6 +27,21 @@ def blocked_lu(a):
     return transp[:min(rows, cols)], nb.value, fz.value
 
 
+def blocked_lu_rowmajor(a):
+    """The same on a C-ordered (row-major) float32/float64 array."""
+    if a.ndim != 2 or a.strides[1] != a.itemsize:
+        raise ValueError("a must be row-major")
+    kind = KIND_OF_DTYPE[a.dtype]
+    rows, cols = a.shape
+    stride = max(1, a.strides[0] // a.itemsize) if rows > 1 else max(1, cols)
+    transp = np.zeros(max(min(rows, cols), 1), dtype=np.int32)
+    nb, fz = ctypes.c_int(0), ctypes.c_int(-1)
+    rc = lib.eigamd_blocked_lu_host_rowmajor(kind, rows, cols, ctypes.c_void_p(a.ctypes.data), stride,
+                                             ctypes.c_void_p(transp.ctypes.data), ctypes.byref(nb), ctypes.byref(fz))
+    _lib.check(rc, "eigamd_blocked_lu_host_rowmajor")
+    return transp[:min(rows, cols)], nb.value, fz.value
+
+
 def getrf(a):
     """LAPACK-style ?getrf_ on a Fortran-ordered array: returns (ipiv 1-based, info)."""
     kind = KIND_OF_DTYPE[a.dtype]

@@ -139,8 +139,23 @@ template <typename T> struct eigamd_lu {
     return first_zero;
   }
 };
+template <typename T> struct eigamd_lu_rowmajor {
+  static Index blocked_lu(Index rows, Index cols, T* lu_data, Index luStride, int* row_transpositions,
+                          int& nb_transpositions, Index /*maxBlockSize*/ = 256) {
+    int first_zero = -1, nb = 0;
+    eigamd_require(eigamd_blocked_lu_host_rowmajor(eigamd_kind<T>::value, rows, cols, lu_data, luStride, row_transpositions, &nb,
+                                                   &first_zero),
+                   "eigamd_blocked_lu_host_rowmajor");
+    nb_transpositions = nb;
+    return first_zero;
+  }
+};
+// Both storage orders, as Eigen/src/LU/PartialPivLU_LAPACKE.h:44-79 binds them (real kinds; a complex
+// PartialPivLU stays on Eigen's own blocked_lu, see eigen_amd_blas.h).
 template <> struct partial_lu_impl<double, ColMajor, int> : eigamd_lu<double> {};
 template <> struct partial_lu_impl<float, ColMajor, int> : eigamd_lu<float> {};
+template <> struct partial_lu_impl<double, RowMajor, int> : eigamd_lu_rowmajor<double> {};
+template <> struct partial_lu_impl<float, RowMajor, int> : eigamd_lu_rowmajor<float> {};
 #endif
 
 }  // namespace internal

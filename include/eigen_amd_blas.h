@@ -176,6 +176,18 @@ int eigamd_fill_uniform_cyclic_dev(int dtype, void* d_x, int64_t rows, int64_t c
  * before returning the two counters. */
 int eigamd_blocked_lu_host(int dtype, int64_t rows, int64_t cols, void* lu, int64_t lu_stride,
                            int* row_transpositions, int* nb_transpositions, int* first_zero_pivot);
+/* The same for a matrix stored row by row (row stride lu_stride >= cols): what
+ * partial_lu_impl<Scalar,RowMajor,int>::blocked_lu factorises (the reference instantiates its blocked_lu for
+ * either storage order, PartialPivLU.h:333-341; its LAPACKE binding passes the order on,
+ * PartialPivLU_LAPACKE.h:50-64).  Same factors, transpositions and counters.
+ *
+ * Complex kinds: the reference also binds cgetrf / zgetrf (PartialPivLU_LAPACKE.h:77-78,
+ * lapack/complex_single.cpp, complex_double.cpp).  This library has no complex LU: the configured
+ * factorisation is double precision real, and the panel kernels (pivot exchange words, rank updates) are
+ * written for real scalars; a complex PartialPivLU stays on Eigen's own blocked_lu, whose trailing update
+ * still reaches this library's zgemm / ztrsm through the product bindings. */
+int eigamd_blocked_lu_host_rowmajor(int dtype, int64_t rows, int64_t cols, void* lu, int64_t lu_stride,
+                                    int* row_transpositions, int* nb_transpositions, int* first_zero_pivot);
 int dgetrf_(const int* m, const int* n, double* a, const int* lda, int* ipiv, int* info);
 int sgetrf_(const int* m, const int* n, float* a, const int* lda, int* ipiv, int* info);
 int eigamd_getrf_dev(int dtype, int64_t m, int64_t n, void* d_a, int64_t lda, int* d_transp,

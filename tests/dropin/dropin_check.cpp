@@ -202,6 +202,21 @@ static void lu_case(int n) {
   expect_close(name, plu.reconstructedMatrix(), m1, 1e-11);  // test/lu.cpp:168
 }
 
+static void lu_case_rowmajor(int n) {
+  typedef Matrix<double, Dynamic, Dynamic, RowMajor> MatR;
+  MatR m1 = MatR::Random(n, n);
+  PartialPivLU<MatR> plu(m1);
+  char name[64];
+  std::snprintf(name, sizeof name, "PartialPivLU<RowMajor MatrixXd>(%d) reconstruct", n);
+  expect_close(name, plu.reconstructedMatrix(), m1, 1e-11);
+  // the same matrix column by column: identical permutation
+  MatrixXd m2 = m1;
+  PartialPivLU<MatrixXd> plu2(m2);
+  const bool same = plu.permutationP().indices() == plu2.permutationP().indices();
+  std::printf("%s %-46s\n", same ? "PASS" : "FAIL", "row-major and column-major LU: same permutation");
+  if (!same) ++g_fail;
+}
+
 template <typename M> __attribute__((noinline)) void gemm_step(const M& a, const M& b, M& c) { c.noalias() += a * b; }
 
 // bench/bench_gemm.cpp:243-246 set-up (A, B random, C ones), three accumulations, then: C must equal
@@ -266,6 +281,7 @@ int main(int argc, char** argv) {
 #endif
   lu_case(100);
   lu_case(1024);
+  lu_case_rowmajor(300);
   std::printf("%s (%d failures)\n", g_fail ? "DROPIN FAIL" : "DROPIN PASS", g_fail);
   return g_fail ? 1 : 0;
 }

@@ -204,3 +204,18 @@ def test_substitution_path_on_ordinary_matrices():
             with env(EIGAMD_LU_INVERSE_LIMIT=0):
                 t2, nb2, r2 = ealu.blocked_lu(a2)
             check_against_oracle(a, a1, t1, a2, t2, exact_pivots=dt == np.float64)
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_rowmajor_storage_gives_the_same_factorisation(dt):
+    """partial_lu_impl<Scalar, RowMajor> (Eigen/src/LU/PartialPivLU.h:333-341): the matrix stored row by
+    row, with a row stride larger than its width, factorises to the same factors and transpositions."""
+    for (m, n) in [(300, 300), (700, 500), (200, 450)]:
+        a = eigen_amd.fill_uniform_host(dt, m, n, 31 + m)
+        col = a.copy(order="F")
+        t1, nb1, r1 = ealu.blocked_lu(col)
+        buf = np.full((m, n + 5), -7.0, dtype=dt)           # C order, row stride n + 5
+        buf[:, :n] = a
+        t2, nb2, r2 = ealu.blocked_lu_rowmajor(buf[:, :n])
+        assert np.array_equal(t1, t2) and nb1 == nb2 and r1 == r2
+        assert np.array_equal(buf[:, :n], col) and (buf[:, n:] == -7.0).all()
