@@ -7,7 +7,8 @@ OUT=$PWD/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 
 
-timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python3 bench.py > $OUT/trace_bench.log 2>&1
+timeout -k 10 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python3 bench.py > $OUT/trace_bench.log 2>&1
+echo "profiler exit status $?" | tee $OUT/trace_exit_status.txt
 grep '^{' $OUT/trace_bench.log > $OUT/bench_under_trace.json || { tail -5 $OUT/trace_bench.log; exit 1; }
 python3 tools/rocpd_summary.py $(find $OUT/trace -name "*.db") > $OUT/kernel_trace_stats_bench.txt
 echo "trace done"
