@@ -154,7 +154,7 @@ template <> struct TileCost<C32> { static constexpr double t0 = 16.0, tk = 0.467
 // 256 workgroups times the tile cost, plus for the split form the pass that adds the partial
 // products up (pieces + 2 matrices at kReduceBytesPerUs, and a launch).
 template <int KIND>
-static int choose_splits(const GemmCall& c, int* k_chunk) {
+static int choose_splits(const GemmCall& c, int* k_chunk, double* cost_out = nullptr) {
   typedef Geometry<KIND> G;
   typedef TileCost<KIND> TC;
   constexpr int kCUs = 256, kMaxSplits = 16;
@@ -177,6 +177,7 @@ static int choose_splits(const GemmCall& c, int* k_chunk) {
     const double cost = rounds(tiles * s) * (TC::t0 + TC::tk * kc) + 6.0 + mn_bytes * (s + 2) / kReduceBytesPerUs;
     if (cost < best) { best = cost; best_s = s; *k_chunk = (int)kc; }
   }
+  if (cost_out) *cost_out = best_s > 1 ? best : whole;
   return best_s;
 }
 
@@ -190,7 +191,7 @@ struct TailPlan {
   int splits, k_chunk;
 };
 template <int KIND>
-static bool choose_tail(const GemmCall& c, TailPlan* plan) {
+static bool choose_tail(const GemmCall& c, TailPlan* plan, double* cost_out = nullptr) {
   typedef Geometry<KIND> G;
   typedef TileCost<KIND> TC;
   constexpr int kCUs = 256, kMaxSplits = 16, kMaxRounds = 12;
@@ -227,6 +228,7 @@ static bool choose_tail(const GemmCall& c, TailPlan* plan) {
       }
     }
   }
+  if (cost_out) *cost_out = best;
   return found;
 }
 
@@ -248,8 +250,16 @@ static hipError_t reduce_partials(const GemmCall& c, int64_t r0, int64_t c0, int
 template <int KIND, bool AK, bool BKC, bool GUARD>
 static hipError_t launch_whole(const GemmCall& c, hipStream_t stream) {
   typedef Geometry<KIND> G;
+  // Three forms, priced by the same model: one launch; one launch with the reduction cut into equal
+  // pieces for every tile; whole rounds of tiles as they are plus the leftover tile rows / columns with
+  // their reduction cut (dgemm 3072^3, 288 tiles: three equal pieces took 1.19 ms, 240 whole tiles plus
+  // 48 tiles in five pieces take less).
   int k_chunk = 0;
-  const int splits = choose_splits<KIND>(c, &k_chunk);
+  double split_cost = 0.0, tail_cost = 0.0;
+  TailPlan t;
+  int splits = choose_splits<KIND>(c, &k_chunk, &split_cost);
+  const bool tail = choose_tail<KIND>(c, &t, &tail_cost);
+  if (splits > 1 && tail && tail_cost < split_cost) splits = 1;
   if (splits > 1) {
     const size_t bytes = (size_t)splits * c.m * c.n * G::ES;
     int slot = -1;
@@ -261,8 +271,7 @@ static hipError_t launch_whole(const GemmCall& c, hipStream_t stream) {
     }
     return launch_region<KIND, AK, BKC, GUARD>(c, 0, 0, c.m, c.n, stream);
   }
-  TailPlan t;
-  if (choose_tail<KIND>(c, &t)) {
+  if (tail) {
     const int64_t r0 = t.by_rows ? t.cut : 0, c0 = t.by_rows ? 0 : t.cut;
     const int64_t rows = c.m - r0, cols = c.n - c0;
     const size_t bytes = (size_t)t.splits * rows * cols * G::ES;
