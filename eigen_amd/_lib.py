@@ -70,7 +70,7 @@ lib.eigamd_laswp_dev.restype = ctypes.c_int
 lib.eigamd_laswp_dev.argtypes = [ctypes.c_int, _vp, _i64, _i64, _vp, ctypes.c_int, ctypes.c_int, _vp]
 lib.eigamd_trsm_llnu_dev.restype = ctypes.c_int
 lib.eigamd_trsm_llnu_dev.argtypes = [ctypes.c_int, _i64, _i64, _vp, _i64, _vp, _i64, _vp]
-for _name in ("dgetrf_", "sgetrf_"):
+for _name in ("dgetrf_", "sgetrf_", "cgetrf_", "zgetrf_"):
     _f = getattr(lib, _name)
     _f.restype = ctypes.c_int
     _f.argtypes = [_i32p, _i32p, _vp, _i32p, _vp, _i32p]

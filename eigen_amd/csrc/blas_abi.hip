@@ -971,7 +971,7 @@ int eigamd_fill_uniform_host(int dtype, void* x, int64_t rows, int64_t cols, int
 
 int eigamd_getrf_dev(int dtype, int64_t m, int64_t n, void* d_a, int64_t lda, int* d_transp,
                      int64_t max_block_size, int* first_zero_pivot, int* nb_transpositions, void* stream) {
-  if (dtype != F32 && dtype != F64) return fail(EIGAMD_ERR_ARG, "LU supports the real kinds (f32, f64)");
+  if (dtype < 0 || dtype > 3) return fail(EIGAMD_ERR_ARG, "invalid dtype");
   if (m < 0 || n < 0 || lda < std::max<int64_t>(1, m) || m > 0x7fffffff || n > 0x7fffffff)
     return fail(EIGAMD_ERR_ARG, "invalid LU arguments");
   int fz = -1, nb = 0;
@@ -992,7 +992,7 @@ int eigamd_getrf_dev(int dtype, int64_t m, int64_t n, void* d_a, int64_t lda, in
 
 int eigamd_getrf_dev_async(int dtype, int64_t m, int64_t n, void* d_a, int64_t lda, int* d_transp, int64_t max_block_size,
                            int* d_info, void* stream) {
-  if (dtype != F32 && dtype != F64) return fail(EIGAMD_ERR_ARG, "LU supports the real kinds (f32, f64)");
+  if (dtype != F32 && dtype != F64) return fail(EIGAMD_ERR_ARG, "the LU that does not wait supports the real kinds (f32, f64)");
   if (m < 1 || n < 1 || lda < m || m > 0x7fffffff || n > 0x7fffffff || !d_info)
     return fail(EIGAMD_ERR_ARG, "invalid LU arguments");
   int rc = ensure_device();
@@ -1067,7 +1067,7 @@ static int lu_host_impl(int dtype, int64_t m, int64_t n, void* a, int64_t lda, i
 
 int eigamd_blocked_lu_host(int dtype, int64_t rows, int64_t cols, void* lu, int64_t lu_stride, int* row_transpositions,
                            int* nb_transpositions, int* first_zero_pivot) {
-  if (dtype != F32 && dtype != F64) return fail(EIGAMD_ERR_ARG, "LU supports the real kinds (f32, f64)");
+  if (dtype < 0 || dtype > 3) return fail(EIGAMD_ERR_ARG, "invalid dtype");
   if (rows < 0 || cols < 0 || lu_stride < std::max<int64_t>(1, rows) || rows > 0x7fffffff || cols > 0x7fffffff)
     return fail(EIGAMD_ERR_ARG, "invalid LU arguments");
   return lu_host_impl(dtype, rows, cols, lu, lu_stride, row_transpositions, first_zero_pivot, nb_transpositions);
@@ -1075,7 +1075,7 @@ int eigamd_blocked_lu_host(int dtype, int64_t rows, int64_t cols, void* lu, int6
 
 int eigamd_blocked_lu_host_rowmajor(int dtype, int64_t rows, int64_t cols, void* lu, int64_t lu_stride, int* row_transpositions,
                                     int* nb_transpositions, int* first_zero_pivot) {
-  if (dtype != F32 && dtype != F64) return fail(EIGAMD_ERR_ARG, "LU supports the real kinds (f32, f64)");
+  if (dtype < 0 || dtype > 3) return fail(EIGAMD_ERR_ARG, "invalid dtype");
   if (rows < 0 || cols < 0 || lu_stride < std::max<int64_t>(1, cols) || rows > 0x7fffffff || cols > 0x7fffffff)
     return fail(EIGAMD_ERR_ARG, "invalid LU arguments");
   return lu_host_impl(dtype, rows, cols, lu, /*lda=*/1, row_transpositions, first_zero_pivot, nb_transpositions, /*inc=*/lu_stride);
@@ -1108,6 +1108,12 @@ int dgetrf_(const int* m, const int* n, double* a, const int* lda, int* ipiv, in
 }
 int sgetrf_(const int* m, const int* n, float* a, const int* lda, int* ipiv, int* info) {
   return f77_getrf(F32, "SGETRF", m, n, a, lda, ipiv, info);
+}
+int cgetrf_(const int* m, const int* n, void* a, const int* lda, int* ipiv, int* info) {   // lapack/complex_single.cpp
+  return f77_getrf(C32, "CGETRF", m, n, a, lda, ipiv, info);
+}
+int zgetrf_(const int* m, const int* n, void* a, const int* lda, int* ipiv, int* info) {   // lapack/complex_double.cpp
+  return f77_getrf(C64, "ZGETRF", m, n, a, lda, ipiv, info);
 }
 
 // ---- ?trsm_ (blas/level3_impl.h:78-178) ---------------------------------------------

@@ -1792,6 +1792,8 @@ hipError_t getrf_device(int kind, int64_t m, int64_t n, void* A, int64_t ld, int
   if (kind == F32)
     return getrf_device_t<float>(m, n, static_cast<float*>(A), ld, d_transp, max_block, first_zero_pivot,
                                  nb_transpositions, s, allow_fused, d_info);
+  if ((kind == C32 || kind == C64) && !d_info)  // the complex driver has no one-launch base case: nothing to turn off
+    return getrf_device_complex(kind, m, n, A, ld, d_transp, max_block, first_zero_pivot, nb_transpositions, s);
   return hipErrorInvalidValue;
 }
 

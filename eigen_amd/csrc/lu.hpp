@@ -5,8 +5,8 @@
 
 namespace eigamd {
 
-// In-place P*A = L*U of the m x n column-major matrix at A (device memory), kind F32
-// or F64.  d_transp (device, min(m,n) ints) receives the 0-based row transpositions
+// In-place P*A = L*U of the m x n column-major matrix at A (device memory), any of the four
+// kinds.  d_transp (device, min(m,n) ints) receives the 0-based row transpositions
 // as global row indices; *first_zero_pivot the index of the first exactly-zero pivot
 // or -1; *nb_transpositions the number of actual row swaps.  Synchronises `s`.
 // max_block is the maxBlockSize of blocked_lu (256 at top level, 16 for a panel).
@@ -22,6 +22,11 @@ hipError_t getrf_device(int kind, int64_t m, int64_t n, void* A, int64_t ld, int
                         int* d_info = nullptr);
 // With d_info (device memory, 3 ints) the call does not wait: behind `s`, d_info holds the first zero
 // pivot or -1, the number of exchanges, and 1 where the call without it would return kLuNotResident.
+
+// The complex kinds (C32, C64) go through a plainer driver (zlu.hip): same algorithm and block rule, per-column
+// kernels for the base case, one stream, no variant that does not wait (d_info must be null for them).
+hipError_t getrf_device_complex(int kind, int64_t m, int64_t n, void* A, int64_t ld, int* d_transp, int64_t max_block,
+                                int* first_zero_pivot, int* nb_transpositions, hipStream_t s);
 
 // Row transpositions i <-> d_transp[i], i in [k0, k1), on ncols columns starting at A
 // (row indices are rows of A).

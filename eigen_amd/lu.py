@@ -11,7 +11,7 @@ from .blas import KIND_OF_DTYPE
 
 
 def blocked_lu(a):
-    """In-place LU of the Fortran-ordered float32/float64 array `a` (rows x cols view of a
+    """In-place LU of the Fortran-ordered float32/float64/complex64/complex128 array `a` (rows x cols view of a
     column-major buffer).  Returns (row_transpositions, nb_transpositions,
     first_zero_pivot) exactly as the reference's blocked_lu reports them."""
     if a.ndim != 2 or a.strides[0] != a.itemsize:
@@ -28,7 +28,7 @@ def blocked_lu(a):
 
 
 def blocked_lu_rowmajor(a):
-    """The same on a C-ordered (row-major) float32/float64 array."""
+    """The same on a C-ordered (row-major) array."""
     if a.ndim != 2 or a.strides[1] != a.itemsize:
         raise ValueError("a must be row-major")
     kind = KIND_OF_DTYPE[a.dtype]
@@ -45,7 +45,7 @@ def blocked_lu_rowmajor(a):
 def getrf(a):
     """LAPACK-style ?getrf_ on a Fortran-ordered array: returns (ipiv 1-based, info)."""
     kind = KIND_OF_DTYPE[a.dtype]
-    fn = {_lib.F32: lib.sgetrf_, _lib.F64: lib.dgetrf_}[kind]
+    fn = {_lib.F32: lib.sgetrf_, _lib.F64: lib.dgetrf_, _lib.C32: lib.cgetrf_, _lib.C64: lib.zgetrf_}[kind]
     m, n = a.shape
     ld = max(1, a.strides[1] // a.itemsize) if n > 1 else max(1, m)
     ipiv = np.zeros(max(min(m, n), 1), dtype=np.int32)

@@ -150,12 +150,15 @@ template <typename T> struct eigamd_lu_rowmajor {
     return first_zero;
   }
 };
-// Both storage orders, as Eigen/src/LU/PartialPivLU_LAPACKE.h:44-79 binds them (real kinds; a complex
-// PartialPivLU stays on Eigen's own blocked_lu, see eigen_amd_blas.h).
+// Both storage orders and the four scalar kinds, as Eigen/src/LU/PartialPivLU_LAPACKE.h:44-79 binds them.
 template <> struct partial_lu_impl<double, ColMajor, int> : eigamd_lu<double> {};
 template <> struct partial_lu_impl<float, ColMajor, int> : eigamd_lu<float> {};
 template <> struct partial_lu_impl<double, RowMajor, int> : eigamd_lu_rowmajor<double> {};
 template <> struct partial_lu_impl<float, RowMajor, int> : eigamd_lu_rowmajor<float> {};
+template <> struct partial_lu_impl<std::complex<double>, ColMajor, int> : eigamd_lu<std::complex<double> > {};
+template <> struct partial_lu_impl<std::complex<float>, ColMajor, int> : eigamd_lu<std::complex<float> > {};
+template <> struct partial_lu_impl<std::complex<double>, RowMajor, int> : eigamd_lu_rowmajor<std::complex<double> > {};
+template <> struct partial_lu_impl<std::complex<float>, RowMajor, int> : eigamd_lu_rowmajor<std::complex<float> > {};
 #endif
 
 }  // namespace internal

@@ -157,7 +157,7 @@ int eigamd_fill_uniform_cyclic_dev(int dtype, void* d_x, int64_t rows, int64_t c
                                    uint64_t seed, int64_t nb_r, int nprow, int myrow, int64_t nb_c,
                                    int npcol, int mycol, void* stream);
 
-/* ---- blocked LU with partial pivoting (real kinds) ----------------------------
+/* ---- blocked LU with partial pivoting ---------------------------------------------
  * The trailing update A22 -= A21*A12 of the blocked factorisation is the GEMM path.
  *
  * eigamd_blocked_lu_host replaces partial_lu_impl<Scalar,ColMajor,int>::blocked_lu
@@ -167,7 +167,7 @@ int eigamd_fill_uniform_cyclic_dev(int dtype, void* d_x, int64_t rows, int64_t c
  * the index of the first exactly-zero pivot or -1.  Same block-size rule, recursion
  * and pivot choice as the reference, so pivots match Eigen's.
  *
- * dgetrf_/sgetrf_ replace EIGEN_LAPACK_FUNC(getrf) (lapack/lu.cpp:14-41): 1-based
+ * sgetrf_/dgetrf_/cgetrf_/zgetrf_ replace EIGEN_LAPACK_FUNC(getrf) (lapack/lu.cpp:14-41): 1-based
  * ipiv, info = -i for a bad argument i (through xerbla_), else first zero pivot + 1.
  *
  * eigamd_getrf_dev factorises a matrix already in HBM; d_transp is device memory
@@ -181,15 +181,17 @@ int eigamd_blocked_lu_host(int dtype, int64_t rows, int64_t cols, void* lu, int6
  * either storage order, PartialPivLU.h:333-341; its LAPACKE binding passes the order on,
  * PartialPivLU_LAPACKE.h:50-64).  Same factors, transpositions and counters.
  *
- * Complex kinds: the reference also binds cgetrf / zgetrf (PartialPivLU_LAPACKE.h:77-78,
- * lapack/complex_single.cpp, complex_double.cpp).  This library has no complex LU: the configured
- * factorisation is double precision real, and the panel kernels (pivot exchange words, rank updates) are
- * written for real scalars; a complex PartialPivLU stays on Eigen's own blocked_lu, whose trailing update
- * still reaches this library's zgemm / ztrsm through the product bindings. */
+ * Complex kinds: the reference's blocked_lu is a template and its bindings include cgetrf / zgetrf
+ * (PartialPivLU_LAPACKE.h:77-78, lapack/complex_single.cpp, complex_double.cpp).  All the LU entry points
+ * here take the four kinds; the pivot of a complex column is its first entry of largest modulus
+ * (scalar_score_coeff_op, PartialPivLU.h:375).  The complex kinds run a plainer driver than the real ones
+ * (per-column kernels, one stream); eigamd_getrf_dev_async is for the real kinds only. */
 int eigamd_blocked_lu_host_rowmajor(int dtype, int64_t rows, int64_t cols, void* lu, int64_t lu_stride,
                                     int* row_transpositions, int* nb_transpositions, int* first_zero_pivot);
 int dgetrf_(const int* m, const int* n, double* a, const int* lda, int* ipiv, int* info);
 int sgetrf_(const int* m, const int* n, float* a, const int* lda, int* ipiv, int* info);
+int cgetrf_(const int* m, const int* n, void* a, const int* lda, int* ipiv, int* info);   /* a: interleaved (re, im) floats */
+int zgetrf_(const int* m, const int* n, void* a, const int* lda, int* ipiv, int* info);   /* a: interleaved (re, im) doubles */
 int eigamd_getrf_dev(int dtype, int64_t m, int64_t n, void* d_a, int64_t lda, int* d_transp,
                      int64_t max_block_size, int* first_zero_pivot, int* nb_transpositions, void* stream);
 /* The same without waiting (m, n >= 1): behind `stream`, the 3 ints at d_info (device memory) hold the first

@@ -1,7 +1,9 @@
 /* CPU oracle for the blocked partial-pivoting LU whose trailing update is the
  * GEMM path: a plain-C restatement of partial_lu_impl::unblocked_lu / blocked_lu
  * (Eigen/src/LU/PartialPivLU.h:357-498) and of the getrf wrapper
- * (lapack/lu.cpp:14-41), for float and double, column-major.
+ * (lapack/lu.cpp:14-41), for float, double and their complex counterparts (the reference's
+ * functions are templates; for a complex scalar the score of an entry is its modulus, std::abs,
+ * PartialPivLU.h:375), column-major.
  *
  * TEST INFRASTRUCTURE ONLY (see gemm_oracle.c).
  *
@@ -15,6 +17,7 @@
  * the trailing update calls the GEMM oracle of gemm_oracle.c; results agree with
  * the reference to rounding, pivots exactly (tests/test_lu_oracle.py).
  */
+#include <complex.h>
 #include <math.h>
 #include <stdlib.h>
 
@@ -23,7 +26,13 @@ void oracle_product64_d(int, int, int, int, long, long, long, const double *, co
 void oracle_product64_s(int, int, int, int, long, long, long, const float *, const float *, long, const float *,
                         long, const float *, float *, long);
 
-#define DEFINE_LU(T, SFX, ABS, PRODUCT)                                                                        \
+void oracle_product64_c(int, int, int, int, long, long, long, const float *, const float *, long, const float *,
+                        long, const float *, float *, long);
+void oracle_product64_z(int, int, int, int, long, long, long, const double *, const double *, long, const double *,
+                        long, const double *, double *, long);
+
+/* T: the scalar; R: the real type of a score and of the pointers the product oracle takes */
+#define DEFINE_LU(T, R, SFX, ABS, PRODUCT)                                                                      \
   /* unblocked_lu, PartialPivLU.h:357-412 (dynamic-size branch: endk = size) */                                \
   static long oracle_unblocked_lu_##SFX(long rows, long cols, T *lu, long ld, int *transp, int *nb_transp) {   \
     const long size = rows < cols ? rows : cols;                                                               \
@@ -31,11 +40,11 @@ void oracle_product64_s(int, int, int, int, long, long, long, const float *, con
     *nb_transp = 0;                                                                                            \
     for (long k = 0; k < size; ++k) {                                                                          \
       long piv = k;                                                                                            \
-      T biggest = ABS(lu[k + k * ld]);                                                                         \
+      R biggest = ABS(lu[k + k * ld]);                                                                         \
       for (long i = k + 1; i < rows; ++i)      /* maxCoeff: first index of the maximum */                      \
         if (ABS(lu[i + k * ld]) > biggest) { biggest = ABS(lu[i + k * ld]); piv = i; }                         \
       transp[k] = (int)piv;                                                                                    \
-      if (biggest != (T)0) {                                                                                   \
+      if (biggest != (R)0) {                                                                                   \
         if (piv != k) {                                                                                        \
           for (long j = 0; j < cols; ++j) { T t = lu[k + j * ld]; lu[k + j * ld] = lu[piv + j * ld]; lu[piv + j * ld] = t; } \
           ++*nb_transp;                                                                                        \
@@ -88,8 +97,8 @@ void oracle_product64_s(int, int, int, int, long, long, long, const float *, con
           }                                                                                                    \
         /* A22 -= A21 * A12 (:494): the GEMM hot path, alpha = -1 */                                           \
         const T minus_one = (T)-1, one = (T)1;                                                                 \
-        PRODUCT(0, 0, 0, 0, trows, tsize, bs, &minus_one, lu + (k + bs) + k * ld, ld, lu + k + (k + bs) * ld, ld, \
-                &one, lu + (k + bs) + (k + bs) * ld, ld);                                                      \
+        PRODUCT(0, 0, 0, 0, trows, tsize, bs, (const R *)&minus_one, (const R *)(lu + (k + bs) + k * ld), ld,  \
+                (const R *)(lu + k + (k + bs) * ld), ld, (const R *)&one, (R *)(lu + (k + bs) + (k + bs) * ld), ld); \
       }                                                                                                        \
     }                                                                                                          \
     return first_zero_pivot;                                                                                   \
@@ -109,5 +118,7 @@ void oracle_product64_s(int, int, int, int, long, long, long, const float *, con
     return 0;                                                                                                  \
   }
 
-DEFINE_LU(double, d, fabs, oracle_product64_d)
-DEFINE_LU(float, s, fabsf, oracle_product64_s)
+DEFINE_LU(double, double, d, fabs, oracle_product64_d)
+DEFINE_LU(float, float, s, fabsf, oracle_product64_s)
+DEFINE_LU(float _Complex, float, c, cabsf, oracle_product64_c)
+DEFINE_LU(double _Complex, double, z, cabs, oracle_product64_z)

@@ -185,6 +185,19 @@ long ref_blocked_lu_s(int64_t rows, int64_t cols, float* a, int64_t lda, int* tr
   return (long)r;
 }
 
+long ref_blocked_lu_c(int64_t rows, int64_t cols, std::complex<float>* a, int64_t lda, int* transp, int* nb_transp) {
+  int nb = 0;
+  Index r = internal::partial_lu_impl<std::complex<float>, ColMajor, int>::blocked_lu(rows, cols, a, lda, transp, nb);
+  *nb_transp = nb;
+  return (long)r;
+}
+long ref_blocked_lu_z(int64_t rows, int64_t cols, std::complex<double>* a, int64_t lda, int* transp, int* nb_transp) {
+  int nb = 0;
+  Index r = internal::partial_lu_impl<std::complex<double>, ColMajor, int>::blocked_lu(rows, cols, a, lda, transp, nb);
+  *nb_transp = nb;
+  return (long)r;
+}
+
 double ref_bench_lu(int64_t n, int tries) {
   typedef Matrix<double, Dynamic, Dynamic> M;
   M a = M::Random(n, n);

@@ -202,6 +202,22 @@ static void lu_case(int n) {
   expect_close(name, plu.reconstructedMatrix(), m1, 1e-11);  // test/lu.cpp:168
 }
 
+template <typename S> static void lu_case_complex(const char* tag, int n, double tol) {
+  typedef Matrix<S, Dynamic, Dynamic> Mat;
+  typedef Matrix<S, Dynamic, Dynamic, RowMajor> MatR;
+  Mat m1 = Mat::Random(n, n);
+  PartialPivLU<Mat> plu(m1);
+  char name[64];
+  std::snprintf(name, sizeof name, "PartialPivLU<%s>(%d) reconstruct", tag, n);
+  expect_close(name, plu.reconstructedMatrix(), m1, tol);
+  MatR m2 = m1;
+  PartialPivLU<MatR> plu2(m2);
+  const bool same = plu.permutationP().indices() == plu2.permutationP().indices();
+  std::snprintf(name, sizeof name, "%s row-major and column-major LU: same P", tag);
+  std::printf("%s %-46s\n", same ? "PASS" : "FAIL", name);
+  if (!same) ++g_fail;
+}
+
 static void lu_case_rowmajor(int n) {
   typedef Matrix<double, Dynamic, Dynamic, RowMajor> MatR;
   MatR m1 = MatR::Random(n, n);
@@ -282,6 +298,8 @@ int main(int argc, char** argv) {
   lu_case(100);
   lu_case(1024);
   lu_case_rowmajor(300);
+  lu_case_complex<std::complex<double> >("MatrixXcd", 300, 1e-11);
+  lu_case_complex<std::complex<float> >("MatrixXcf", 300, 1e-4);
   std::printf("%s (%d failures)\n", g_fail ? "DROPIN FAIL" : "DROPIN PASS", g_fail);
   return g_fail ? 1 : 0;
 }

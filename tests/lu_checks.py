@@ -1,12 +1,12 @@
 """Shared checks of the LU parity tests.
 
-Pivot rule.  The oracle and the device run the same algorithm (first row of largest |a|,
-Eigen/src/LU/PartialPivLU.h:375-377) but not the same roundings: the rank-16 and rank-256
+Pivot rule.  The oracle and the device run the same algorithm (first row of largest |a|, the modulus
+for a complex scalar, Eigen/src/LU/PartialPivLU.h:375-377) but not the same roundings: the rank-16 and rank-256
 updates are fused multiply-adds summed in another order.  Two candidates of a column whose
 magnitudes differ by less than the rounding the column has accumulated may therefore swap
 places.  What is demanded:
-  * float64: identical transpositions (holds for every case on file);
-  * float32: identical transpositions up to the first column j where they differ; there the
+  * float64, complex128: identical transpositions (holds for every case on file);
+  * float32, complex64: identical transpositions up to the first column j where they differ; there the
     device's choice must be a near-tie of the oracle's:
         |pivot_oracle| - |candidate_device| <= 8 * eps * (j + 1) * |pivot_oracle|
     (both magnitudes read from the oracle's factors: |l_rj| * |u_jj|, the row located through the
@@ -30,9 +30,10 @@ def residual(a0, lu, transp):
     """|| P*A - L*U ||_F / || A ||_F on the leading min(m,n) columns the blocked algorithm covers."""
     m, n = a0.shape
     size = min(m, n)
-    pa = a0.astype(np.float64)[perm_of(transp, m)]
-    l = np.tril(lu[:, :size].astype(np.float64), -1) + np.eye(m, size)
-    u = np.triu(lu[:size, :].astype(np.float64))
+    wide = np.complex128 if np.iscomplexobj(a0) else np.float64
+    pa = a0.astype(wide)[perm_of(transp, m)]
+    l = np.tril(lu[:, :size].astype(wide), -1) + np.eye(m, size)
+    u = np.triu(lu[:size, :].astype(wide))
     cols = n if m <= 16 else size          # the reference's blocked branch never touches columns >= size
     return np.linalg.norm((pa - l @ u)[:, :cols]) / np.linalg.norm(a0)
 
@@ -41,7 +42,8 @@ def check_structure(lu, transp, m, n):
     size = min(m, n)
     t = np.asarray(transp)
     assert (t >= np.arange(size)).all() and (t < m).all(), "a transposition names a row above the diagonal or out of range"
-    assert np.abs(np.tril(lu[:, :size], -1)).max(initial=0.0) <= 1.0, "|l_ij| > 1"
+    slack = 4 * np.finfo(lu.dtype).eps if np.iscomplexobj(lu) else 0.0   # a complex quotient of modulus 1 is rounded
+    assert np.abs(np.tril(lu[:, :size], -1)).max(initial=0.0) <= 1.0 + slack, "|l_ij| > 1"
 
 
 def check_against_oracle(a0, lu_or, t_or, lu_dev, t_dev, exact_pivots):
@@ -56,7 +58,7 @@ def check_against_oracle(a0, lu_or, t_or, lu_dev, t_dev, exact_pivots):
     diff = np.nonzero(np.asarray(t_or) != np.asarray(t_dev))[0]
     if diff.size == 0:
         scale = np.abs(lu_or).max()
-        err = np.abs(lu_or.astype(np.float64) - lu_dev.astype(np.float64)).max()
+        err = np.abs(lu_or.astype(np.complex128) - lu_dev.astype(np.complex128)).max()
         assert err <= 64 * eps * max(m, n) * scale, (m, n, err)
         return None
     j = int(diff[0])
@@ -71,8 +73,8 @@ def check_against_oracle(a0, lu_or, t_or, lu_dev, t_dev, exact_pivots):
             row = p
         elif row == p:
             row = i
-    piv = abs(float(lu_or[j, j]))
-    cand = abs(float(lu_or[row, j])) * piv
+    piv = float(abs(lu_or[j, j]))
+    cand = float(abs(lu_or[row, j])) * piv
     assert piv - cand <= 8 * eps * (j + 1) * piv, \
         f"column {j}: device pivot row {p_dev} (|a| = {cand}) is no near-tie of the oracle's row {p_or} (|a| = {piv})"
     assert size > 0

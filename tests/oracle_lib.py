@@ -19,7 +19,7 @@ EPS = [2.0 ** -23, 2.0 ** -52, 2.0 ** -23, 2.0 ** -52]  # machine epsilon per ki
 if not os.path.exists(ORACLE_SO):
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "_build/liboracle.so"])
 oracle = ctypes.CDLL(ORACLE_SO, mode=ctypes.RTLD_GLOBAL)
-for _sfx in "sd":
+for _sfx in "sdcz":
     _f = getattr(oracle, "oracle_blocked_lu_" + _sfx)
     _f.restype = ctypes.c_long
     _f.argtypes = [ctypes.c_long, ctypes.c_long, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p,
@@ -65,7 +65,7 @@ def load_ref(variant=None):
         ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
     lib.ref_simd.restype = ctypes.c_char_p
     lib.ref_set_cache_sizes.argtypes = [ctypes.c_long] * 3
-    for name in ("ref_blocked_lu_d", "ref_blocked_lu_s"):
+    for name in ("ref_blocked_lu_d", "ref_blocked_lu_s", "ref_blocked_lu_c", "ref_blocked_lu_z"):
         f = getattr(lib, name)
         f.restype = ctypes.c_long
         f.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]

@@ -50,6 +50,23 @@ def test_xerbla_name_and_info():
     ol.reset_xerbla()
 
 
+@pytest.mark.parametrize("name", ["sgetrf_", "dgetrf_", "cgetrf_", "zgetrf_"])
+def test_getrf_argument_errors(name):
+    a = np.zeros(64, dtype=np.complex128)
+    ipiv = np.zeros(4, dtype=np.int32)
+    i = lambda v: ctypes.byref(ctypes.c_int(v))
+    for (m, n, lda, code) in [(-1, 4, 4, 1), (4, -1, 4, 2), (4, 4, 3, 4)]:      # lapack/lu.cpp:16-24
+        info = ctypes.c_int(0)
+        ol.reset_xerbla()
+        getattr(_lib.lib, name)(i(m), i(n), ctypes.c_void_p(a.ctypes.data), i(lda), ctypes.c_void_p(ipiv.ctypes.data),
+                                ctypes.byref(info))
+        assert info.value == -code and ol.last_xerbla() == (code, name[:-1].upper())
+    info = ctypes.c_int(5)
+    getattr(_lib.lib, name)(i(0), i(4), ctypes.c_void_p(a.ctypes.data), i(1), ctypes.c_void_p(ipiv.ctypes.data),
+                            ctypes.byref(info))                                     # quick return, no device needed
+    assert info.value == 0
+
+
 def test_quick_returns_need_no_device():
     c = np.full((3, 3), 7.0, order="F")
     a = np.ones((3, 3), order="F")

@@ -1,6 +1,8 @@
 """Pins the LU oracle (oracle/lu_oracle.c) against the reference's own blocked_lu:
 identical pivots and zero-pivot bookkeeping, factors equal to rounding (bitwise for
-the unblocked base case against the scalar build)."""
+the unblocked base case against the scalar build; for the complex kinds the column scaling
+l = a / pivot is the textbook quotient in the oracle (-fcx-limited-range) and the scaled one of
+std::complex in the reference, so those factors agree to rounding only)."""
 import ctypes
 
 import numpy as np
@@ -12,9 +14,18 @@ SHAPES = [(1, 1), (5, 5), (16, 16), (17, 17), (40, 40), (100, 100), (129, 129), 
           (200, 300), (10, 40)]
 
 
+SFX = {np.float32: "s", np.float64: "d", np.complex64: "c", np.complex128: "z"}
+
+
+def random_matrix(rng, shape, dt):
+    a = rng.uniform(-1, 1, shape)
+    if np.issubdtype(dt, np.complexfloating):
+        a = a + 1j * rng.uniform(-1, 1, shape)
+    return np.asfortranarray(a.astype(dt))
+
+
 def oracle_lu(a, max_block=256):
-    dt = a.dtype
-    sfx = "d" if dt == np.float64 else "s"
+    sfx = SFX[a.dtype.type]
     m, n = a.shape
     t = np.zeros(max(min(m, n), 1), dtype=np.int32)
     nb = ctypes.c_int()
@@ -25,7 +36,7 @@ def oracle_lu(a, max_block=256):
 
 
 def ref_lu(ref, a):
-    sfx = "d" if a.dtype == np.float64 else "s"
+    sfx = SFX[a.dtype.type]
     m, n = a.shape
     t = np.zeros(max(min(m, n), 1), dtype=np.int32)
     nb = ctypes.c_int()
@@ -38,18 +49,19 @@ def residual(a0, lu, transp):
     """|| P*A - L*U ||_F / || A ||_F on the leading min(m,n) columns the blocked algorithm covers."""
     m, n = a0.shape
     size = min(m, n)
-    pa = a0.astype(np.float64).copy()
+    wide = np.complex128 if np.iscomplexobj(a0) else np.float64
+    pa = a0.astype(wide).copy()
     for i, p in enumerate(transp):
         if p != i:
             pa[[i, p], :] = pa[[p, i], :]
-    l = np.tril(lu[:, :size].astype(np.float64), -1) + np.eye(m, size)
-    u = np.triu(lu[:size, :].astype(np.float64))
+    l = np.tril(lu[:, :size].astype(wide), -1) + np.eye(m, size)
+    u = np.triu(lu[:size, :].astype(wide))
     cols = n if m <= 16 else size          # the reference's blocked branch never touches columns >= size
     return np.linalg.norm((pa - l @ u)[:, :cols]) / np.linalg.norm(a0)
 
 
 @pytest.mark.parametrize("variant", ["novec", "v3"])
-@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("dt", [np.float64, np.float32, np.complex128, np.complex64])
 def test_lu_oracle_vs_reference(variant, dt):
     ref = ol.load_ref(variant)
     if ref is None:
@@ -59,13 +71,13 @@ def test_lu_oracle_vs_reference(variant, dt):
     eps = np.finfo(dt).eps
     for (m, n) in SHAPES:
         rng = np.random.default_rng(m * 1000 + n)
-        a = np.asfortranarray(rng.uniform(-1, 1, (m + 3, n)).astype(dt))
+        a = random_matrix(rng, (m + 3, n), dt)
         a1, a2 = a.copy(order="F"), a.copy(order="F")
         t1, nb1, r1 = oracle_lu(a1[:m])
         t2, nb2, r2 = ref_lu(ref, a2[:m])
         assert np.array_equal(t1, t2) and nb1 == nb2 and r1 == r2 == -1
         assert np.array_equal(a1[m:], a[m:])  # padding rows untouched
-        if min(m, n) <= 16 and variant == "novec":
+        if min(m, n) <= 16 and variant == "novec" and not np.iscomplexobj(a):
             assert np.array_equal(a1, a2)
         else:
             assert np.abs(a1[:m] - a2[:m]).max() <= 64 * eps * max(m, n) * np.abs(a2[:m]).max()
