@@ -1248,6 +1248,7 @@ template <typename T> struct Workspace {
   int fused_capacity;   // workgroups of lu_base_fused that are certainly resident together
   BaseCaseRule rule;
   int64_t wide_fixed, wide_t4, wide_t2;  // outer-step width rule of the look-ahead (outer_block)
+  int64_t split_min;    // the bulk update is dealt over two streams while at least this many columns remain (0: never)
   // Scratch of lu_swap_plan / lu_apply_plan and inverses of unit lower triangles (kPlanSpan^2
   // each).  Sets [2 * kMaxSub): the look-ahead, alternating per outer step, one entry per
   // kPlanSpan-wide piece of the step's block; the last set: blocked() itself (one stream).
@@ -1455,6 +1456,10 @@ hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows
 struct LuStreams {
   hipStream_t panel = nullptr;
   hipStream_t update = nullptr;    // null: the caller's stream does the updates
+  hipStream_t update2 = nullptr;   // second update stream (same CUs as `update`): the right part of a split trailing update
+  hipEvent_t left_done[2] = {nullptr, nullptr};   // update  -> update2: left part of step k (parity k & 1) updated
+  hipEvent_t right_done[2] = {nullptr, nullptr};  // update2 -> update, panel: right part of step k updated, scratch of step k free
+  hipEvent_t resplit = nullptr;    // update -> update2: everything queued before the columns were dealt anew
   hipEvent_t ready = nullptr;      // update -> panel: next panel's columns are current
   hipEvent_t factored = nullptr;   // panel -> update: panel factorised, transpositions known
   hipEvent_t fork = nullptr;       // caller's stream -> update stream
@@ -1507,21 +1512,33 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
     upd = st.update;
   }
   LU_TRY(hipEventRecord(st.ready, upd));  // everything queued before the call
+  // The bulk of a step's trailing update may be dealt over two streams that share the update CUs: `upd`
+  // takes the columns [lo, mid), `upd2` the columns [mid, size).  Each part is the same chain as before
+  // (transpositions, solve, product) on its own columns, so nothing changes per element; what changes is
+  // that the memory-bound transpositions and the few-workgroup solve of one part run beside the product
+  // of the other instead of in front of it.  `mid` stays where it is from step to step (the right part
+  // never changes hands, the left part shrinks) until the left part has become small; then the columns are
+  // dealt anew, `upd` waiting for the right part's last step before it touches any of those columns.
+  hipStream_t upd2 = (st.update && st.update2 && w.split_min > 0) ? st.update2 : nullptr;
+  int64_t mid = -1;                          // first column of the right part; -1: the update is not split
+  bool right_recorded[2] = {false, false};   // right_done[parity] has been recorded in this call
   int step = 0;
   for (int64_t k = 0, bs = 0; k < size; k += bs, ++step) {
     bs = std::min(size - k, outer_block(wr, size - k, rule_block));
     const int64_t trows = rows - k - bs, tsize = size - k - bs;
+    const int par = step & 1;
     // The step's block in pieces of at most kPlanSpan rows: one swap plan and one inverted
     // triangle per piece.  Per-step scratch alternates: the panel stream prepares step k+1
-    // while the update stream still uses what belongs to step k.
+    // while the update streams still use what belongs to step k.
     const int nsub = (int)((bs + kPlanSpan - 1) / kPlanSpan);
-    SwapPlan* const* plan = &w.plan[(step & 1) * kMaxSub];
-    T* const* linv = &w.linv[(step & 1) * kMaxSub];
-    int* const* linv_flag = &w.linv_flag[(step & 1) * kMaxSub];
+    SwapPlan* const* plan = &w.plan[par * kMaxSub];
+    T* const* linv = &w.linv[par * kMaxSub];
+    int* const* linv_flag = &w.linv_flag[par * kMaxSub];
     auto sub_begin = [&](int i) { return (int64_t)i * kPlanSpan; };
     auto sub_size = [&](int i) { return std::min<int64_t>(kPlanSpan, bs - sub_begin(i)); };
     const bool planned = bs > 32;
     LU_TRY(hipStreamWaitEvent(pan, st.ready, 0));
+    if (right_recorded[par]) LU_TRY(hipStreamWaitEvent(pan, st.right_done[par], 0));  // (this parity's scratch: step - 2)
     LU_TRY(blocked<T>(A, ld, k, k, trows + bs, bs, transp, 16, w, pan, bs > rule_block ? rule_block : 0));
     if (planned)
       for (int i = 0; i < nsub; ++i)
@@ -1529,46 +1546,77 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
     if (trows > 0)
       for (int i = 0; i < nsub; ++i)
         if (inverse_applies<T>(sub_size(i)))
-          LU_TRY(make_inverse<T>(A + (k + sub_begin(i)) * (ld + 1), ld, sub_size(i), linv[i], linv_flag[i], w.linv_max[(step & 1) * kMaxSub + i], w.inverse_limit, pan));
+          LU_TRY(make_inverse<T>(A + (k + sub_begin(i)) * (ld + 1), ld, sub_size(i), linv[i], linv_flag[i], w.linv_max[par * kMaxSub + i], w.inverse_limit, pan));
     LU_TRY(hipEventRecord(st.factored, pan));
     LU_TRY(hipStreamWaitEvent(upd, st.factored, 0));
     // the step's transpositions, in order, on `ncols` columns
-    auto swap_rows = [&](T* cols, int64_t ncols) -> hipError_t {
-      if (!planned) return laswp<T>(cols, ld, ncols, transp, (int)k, (int)(k + bs), nullptr, upd);
-      for (int i = 0; i < nsub; ++i) LU_TRY(apply_plan<T>(cols, ld, ncols, plan[i], upd));
+    auto swap_rows = [&](T* cols, int64_t ncols, hipStream_t q) -> hipError_t {
+      if (!planned) return laswp<T>(cols, ld, ncols, transp, (int)k, (int)(k + bs), nullptr, q);
+      for (int i = 0; i < nsub; ++i) LU_TRY(apply_plan<T>(cols, ld, ncols, plan[i], q));
       return hipSuccess;
     };
     // A12 <- L^-1 A12 with L the unit lower triangle of the step's bs x bs block, piece by piece:
     // the piece's own triangle (inverted where that applies), then the rows of the later pieces.
-    auto solve = [&](T* A12, int64_t ncols) -> hipError_t {
+    auto solve = [&](T* A12, int64_t ncols, hipStream_t q) -> hipError_t {
       for (int i = 0; i < nsub; ++i) {
         const int64_t o = sub_begin(i), sb = sub_size(i);
         const T* L = A + (k + o) * (ld + 1);
-        if (inverse_applies<T>(sb)) LU_TRY(apply_inverse<T>(linv[i], linv_flag[i], L, ld, sb, A12 + o, ld, ncols, upd));
-        else LU_TRY(trsm_unit_lower<T>(L, A12 + o, ld, sb, ncols, upd));
-        if (o + sb < bs) LU_TRY(gemm_minus3<T>(bs - o - sb, ncols, sb, L + sb, ld, A12 + o, ld, A12 + o + sb, ld, upd));
+        if (inverse_applies<T>(sb)) LU_TRY(apply_inverse<T>(linv[i], linv_flag[i], L, ld, sb, A12 + o, ld, ncols, q));
+        else LU_TRY(trsm_unit_lower<T>(L, A12 + o, ld, sb, ncols, q));
+        if (o + sb < bs) LU_TRY(gemm_minus3<T>(bs - o - sb, ncols, sb, L + sb, ld, A12 + o, ld, A12 + o + sb, ld, q));
       }
       return hipSuccess;
     };
     T* A21 = A + (k + bs) + k * ld;
-    // columns of the next step's block first
     const int64_t nb = trows ? std::min<int64_t>(tsize, outer_block(wr, tsize, rule_block)) : 0;
+    // how the columns [lo, size) right of the next step's block are dealt in this step
+    const int64_t lo = k + bs + nb, rest = trows ? tsize - nb : 0;
+    const bool split = upd2 != nullptr && planned && rest >= w.split_min;
+    bool dealt_anew = false;
+    if (split ? (mid < 0 || mid - lo < (size - mid) / 3) : mid >= 0) {
+      // `upd` is about to touch columns that were the right part's (or stops leaving them alone)
+      if (step > 0 && right_recorded[par ^ 1]) LU_TRY(hipStreamWaitEvent(upd, st.right_done[par ^ 1], 0));
+      mid = split ? lo + rest / 2 / kPlanSpan * kPlanSpan : -1;
+      dealt_anew = split;
+    }
+    // columns of the next step's block first
     if (nb > 0) {
       T* A12 = A + k + (k + bs) * ld;
-      LU_TRY(swap_rows(A + (k + bs) * ld, nb));
-      LU_TRY(solve(A12, nb));
+      LU_TRY(swap_rows(A + (k + bs) * ld, nb, upd));
+      LU_TRY(solve(A12, nb, upd));
       LU_TRY(gemm_minus<T>(trows, nb, bs, A21, A12, A12 + bs, ld, upd));
     }
     LU_TRY(hipEventRecord(st.ready, upd));
-    // columns to the left (A_0), then the rest of the trailing matrix (A_2)
-    LU_TRY(swap_rows(A, k));
-    if (trows && tsize > nb) {
-      T* A12 = A + k + (k + bs + nb) * ld;
-      LU_TRY(swap_rows(A + (k + bs + nb) * ld, tsize - nb));
-      LU_TRY(solve(A12, tsize - nb));
-      LU_TRY(gemm_minus<T>(trows, tsize - nb, bs, A21, A12, A12 + bs, ld, upd));
+    if (dealt_anew) {
+      LU_TRY(hipEventRecord(st.resplit, upd));
+      LU_TRY(hipStreamWaitEvent(upd2, st.resplit, 0));
     }
+    auto bulk = [&](int64_t c0, int64_t c1, hipStream_t q) -> hipError_t {  // trailing columns [c0, c1)
+      if (c1 <= c0) return hipSuccess;
+      T* A12 = A + k + c0 * ld;
+      LU_TRY(swap_rows(A + c0 * ld, c1 - c0, q));
+      LU_TRY(solve(A12, c1 - c0, q));
+      return gemm_minus<T>(trows, c1 - c0, bs, A21, A12, A12 + bs, ld, q);
+    };
+    if (!split) {
+      // columns to the left (A_0), then the rest of the trailing matrix (A_2)
+      LU_TRY(swap_rows(A, k, upd));
+      if (trows && rest > 0) LU_TRY(bulk(lo, size, upd));
+    } else {
+      LU_TRY(bulk(lo, mid, upd));
+      LU_TRY(hipStreamWaitEvent(upd2, st.factored, 0));
+      LU_TRY(bulk(mid, size, upd2));
+      // The columns to the left: behind the products of the previous step on BOTH streams (they read the
+      // previous block's columns, which these transpositions move), and in step order -- hence here.
+      if (step > 0) LU_TRY(hipStreamWaitEvent(upd2, st.left_done[par ^ 1], 0));
+      LU_TRY(swap_rows(A, k, upd2));
+      LU_TRY(hipEventRecord(st.right_done[par], upd2));
+      right_recorded[par] = true;
+    }
+    LU_TRY(hipEventRecord(st.left_done[par], upd));
   }
+  for (int p = 0; p < 2; ++p)
+    if (right_recorded[p]) LU_TRY(hipStreamWaitEvent(upd, st.right_done[p], 0));
   // the panel stream has nothing queued after the last `factored` event
   if (st.update) {
     LU_TRY(hipEventRecord(st.join, upd));
@@ -1601,13 +1649,14 @@ void release_lu_streams() {
     LuScratch& sc = scratch();
     std::lock_guard<std::mutex> lock(sc.mu);
     LuStreams& st = sc.streams;
-    for (hipStream_t* q : {&st.panel, &st.update})
+    for (hipStream_t* q : {&st.panel, &st.update, &st.update2})
       if (*q) {
         (void)hipStreamSynchronize(*q);
         (void)hipStreamDestroy(*q);
         *q = nullptr;
       }
-    for (hipEvent_t* e : {&st.ready, &st.factored, &st.fork, &st.join})
+    for (hipEvent_t* e : {&st.ready, &st.factored, &st.fork, &st.join, &st.resplit, &st.left_done[0], &st.left_done[1],
+                          &st.right_done[0], &st.right_done[1]})
       if (*e) {
         (void)hipEventDestroy(*e);
         *e = nullptr;
@@ -1644,13 +1693,16 @@ hipError_t make_streams(LuStreams& st, int base_workgroups, int per_cu, int* tot
     LU_TRY(hipStreamDestroy(st.panel));
     st.panel = nullptr;
 
-    if (st.update) {
-      LU_TRY(hipStreamSynchronize(st.update));
-      LU_TRY(hipStreamDestroy(st.update));
-      st.update = nullptr;
-    }
+    for (hipStream_t* q : {&st.update, &st.update2})
+      if (*q) {
+        LU_TRY(hipStreamSynchronize(*q));
+        LU_TRY(hipStreamDestroy(*q));
+        *q = nullptr;
+      }
   }
   if (!st.ready) {
+    for (hipEvent_t* e : {&st.resplit, &st.left_done[0], &st.left_done[1], &st.right_done[0], &st.right_done[1]})
+      LU_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     LU_TRY(hipEventCreateWithFlags(&st.ready, hipEventDisableTiming));
     LU_TRY(hipEventCreateWithFlags(&st.factored, hipEventDisableTiming));
     LU_TRY(hipEventCreateWithFlags(&st.fork, hipEventDisableTiming));
@@ -1666,7 +1718,7 @@ hipError_t make_streams(LuStreams& st, int base_workgroups, int per_cu, int* tot
     for (int b = 0; b < total; ++b) (b >= total - want ? pmask : umask)[b / 32] |= 1u << (b % 32);
     LU_TRY(hipExtStreamCreateWithCUMask(&st.panel, (uint32_t)words, pmask.data()));
     LU_TRY(hipExtStreamCreateWithCUMask(&st.update, (uint32_t)words, umask.data()));
-
+    LU_TRY(hipExtStreamCreateWithCUMask(&st.update2, (uint32_t)words, umask.data()));
   }
   st.panel_cus = want;
   // The streams with a compute-unit mask are given back before the process's libraries shut down.  (Left to
@@ -1720,6 +1772,8 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   {
     const WidthRule wr = read_width_rule();
     w.wide_fixed = wr.fixed; w.wide_t4 = wr.t4; w.wide_t2 = wr.t2;
+    w.split_min = 8192;
+    if (const char* e = getenv("EIGAMD_LU_SPLIT_MIN")) w.split_min = atoll(e);
   }
   w.first_zero = reinterpret_cast<int*>(p);
   w.nswaps = w.first_zero + 1;
