@@ -1248,6 +1248,7 @@ template <typename T> struct Workspace {
   int fused_capacity;   // workgroups of lu_base_fused that are certainly resident together
   BaseCaseRule rule;
   int64_t wide_fixed, wide_t4, wide_t2;  // outer-step width rule of the look-ahead (outer_block)
+  bool ramp;            // the first outer steps of the look-ahead are narrower than the rule's width
   int64_t split_min;    // the bulk update is dealt over two streams while at least this many columns remain (0: never)
   // Scratch of lu_swap_plan / lu_apply_plan and inverses of unit lower triangles (kPlanSpan^2
   // each).  Sets [2 * kMaxSub): the look-ahead, alternating per outer step, one entry per
@@ -1523,8 +1524,15 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
   int64_t mid = -1;                          // first column of the right part; -1: the update is not split
   bool right_recorded[2] = {false, false};   // right_done[parity] has been recorded in this call
   int step = 0;
+  // Width of step `i` when `remaining` columns are left.  The first steps ramp up (one panel, two panels,
+  // then the rule's width): nothing runs beside the very first panel, so it should be short.
+  auto width_at = [&](int i, int64_t remaining) {
+    int64_t wdt = outer_block(wr, remaining, rule_block);
+    if (w.ramp && wr.fixed == 0 && i < 2) wdt = std::min<int64_t>(wdt, (int64_t)kPlanSpan << i);
+    return std::min(remaining, wdt);
+  };
   for (int64_t k = 0, bs = 0; k < size; k += bs, ++step) {
-    bs = std::min(size - k, outer_block(wr, size - k, rule_block));
+    bs = width_at(step, size - k);
     const int64_t trows = rows - k - bs, tsize = size - k - bs;
     const int par = step & 1;
     // The step's block in pieces of at most kPlanSpan rows: one swap plan and one inverted
@@ -1568,7 +1576,7 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
       return hipSuccess;
     };
     T* A21 = A + (k + bs) + k * ld;
-    const int64_t nb = trows ? std::min<int64_t>(tsize, outer_block(wr, tsize, rule_block)) : 0;
+    const int64_t nb = (trows && tsize > 0) ? width_at(step + 1, tsize) : 0;
     // how the columns [lo, size) right of the next step's block are dealt in this step
     const int64_t lo = k + bs + nb, rest = trows ? tsize - nb : 0;
     const bool split = upd2 != nullptr && planned && rest >= w.split_min;
@@ -1773,6 +1781,8 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
     const WidthRule wr = read_width_rule();
     w.wide_fixed = wr.fixed; w.wide_t4 = wr.t4; w.wide_t2 = wr.t2;
     w.split_min = 8192;
+    w.ramp = true;
+    if (const char* e = getenv("EIGAMD_LU_RAMP")) w.ramp = atoi(e) != 0;
     if (const char* e = getenv("EIGAMD_LU_SPLIT_MIN")) w.split_min = atoll(e);
   }
   w.first_zero = reinterpret_cast<int*>(p);
