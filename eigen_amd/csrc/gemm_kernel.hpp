@@ -30,6 +30,8 @@
 namespace eigamd {
 
 enum Kind : int { F32 = 0, F64 = 1, C32 = 2, C64 = 3 };
+// A second tile geometry for double, used by the launcher for products of few large tiles (never a caller's kind).
+constexpr int F64S = 4;
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef float f16_t __attribute__((ext_vector_type(16)));
@@ -79,6 +81,11 @@ struct GemmParams {
 #ifndef EIGAMD_F32_SHAPE
 #define EIGAMD_F32_SHAPE 2, 4, 4, 2, 32, 1, 1, 1, 2
 #endif
+// double, 128 x 64 tile, two workgroups per CU: a quarter of the large tile's work per workgroup, for products that
+// would leave most compute units without a tile (or with a long single one).
+#ifndef EIGAMD_F64S_SHAPE
+#define EIGAMD_F64S_SHAPE 2, 2, 4, 2, 16, 2, 1, 1, 2
+#endif
 #ifndef EIGAMD_C64_SHAPE
 #define EIGAMD_C64_SHAPE 2, 4, 4, 2, 16, 1, 1, 1, 2
 #endif
@@ -124,6 +131,10 @@ template <> struct Traits<F64> {
   static constexpr int WM = S::WM, WN = S::WN, MT = S::MT, NT = S::NT, BK = S::BK;
   static constexpr int PADX = 16, PADK = 2;
   static constexpr bool kVecWriteK = true;
+};
+template <> struct Traits<F64S> : Traits<F64> {
+  typedef Shape<EIGAMD_F64S_SHAPE> S;
+  static constexpr int WM = S::WM, WN = S::WN, MT = S::MT, NT = S::NT, BK = S::BK;
 };
 template <> struct Traits<C32> {
   typedef float2 Elem;

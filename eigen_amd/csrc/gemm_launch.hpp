@@ -45,6 +45,8 @@ struct Tuning {
 // per k-step in that XCD's L2: 4 x 8 tiles of 256 x 128 for f64 (L2 hit 80 % against 65 % with
 // groups of 8, L2 <-> fabric reads per 16384^3 product 80 GB against 148 GB), 8 x 4 for the others.
 template <int KIND> constexpr int default_group_m() { return KIND == F64 ? 4 : 8; }
+// Workgroups of a kind's kernel that share a compute unit.
+template <int KIND> constexpr int workgroups_per_cu() { return Traits<KIND>::S::PER_CU; }
 
 inline const Tuning& tuning() {
   static const Tuning t = [] {
@@ -91,6 +93,7 @@ hipError_t launch_gemm_f32(const GemmCall&, hipStream_t);
 hipError_t launch_gemm_f64(const GemmCall&, hipStream_t);
 hipError_t launch_gemm_c32(const GemmCall&, hipStream_t);
 hipError_t launch_gemm_c64(const GemmCall&, hipStream_t);
+hipError_t launch_gemm_f64_small(const GemmCall&, hipStream_t);  // the 128 x 64 tile (gemm_inst_f64s.hip)
 
 template <int KIND, bool AK, bool BKC, bool GUARD>
 static hipError_t launch_region(const GemmCall& c, int64_t r0, int64_t c0, int64_t rows,
@@ -147,6 +150,8 @@ template <> struct TileCost<F64> { static constexpr double t0 = 13.0, tk = 0.240
 template <> struct TileCost<F32> { static constexpr double t0 = 29.0, tk = 0.234; };
 template <> struct TileCost<C64> { static constexpr double t0 = 13.0, tk = 0.467; };
 template <> struct TileCost<C32> { static constexpr double t0 = 16.0, tk = 0.467; };
+// (per workgroup with two on a compute unit: 128 x 64 x k at about 0.8 of half a CU's rate)
+template <> struct TileCost<F64S> { static constexpr double t0 = 9.0, tk = 0.125; };
 
 // A product of few tiles leaves most of the 256 compute units idle while each busy one walks the
 // whole reduction (dgemm 1024^3: 32 tiles, 0.26 ms, 8 TFLOP/s).  Returns how many pieces to cut
@@ -157,7 +162,7 @@ template <int KIND>
 static int choose_splits(const GemmCall& c, int* k_chunk, double* cost_out = nullptr) {
   typedef Geometry<KIND> G;
   typedef TileCost<KIND> TC;
-  constexpr int kCUs = 256, kMaxSplits = 16;
+  constexpr int kCUs = 256 * workgroups_per_cu<KIND>(), kMaxSplits = 16;  // (workgroups that run side by side)
   constexpr size_t kMaxBytes = (size_t)256 << 20;
   *k_chunk = (int)c.k;
   if (c.tri || c.ktri || c.serial_edges || c.k < 8 * G::BK) return 1;
@@ -194,7 +199,7 @@ template <int KIND>
 static bool choose_tail(const GemmCall& c, TailPlan* plan, double* cost_out = nullptr) {
   typedef Geometry<KIND> G;
   typedef TileCost<KIND> TC;
-  constexpr int kCUs = 256, kMaxSplits = 16, kMaxRounds = 12;
+  constexpr int kCUs = 256 * workgroups_per_cu<KIND>(), kMaxSplits = 16, kMaxRounds = 12;
   constexpr size_t kMaxBytes = (size_t)256 << 20;
   if (c.tri || c.ktri || c.serial_edges || c.k < 8 * G::BK) return false;
   static const bool off = [] { const char* e = std::getenv("EIGAMD_TAILSPLIT"); return e && std::atoi(e) == 0; }();
@@ -289,6 +294,28 @@ static hipError_t launch_whole(const GemmCall& c, hipStream_t stream) {
     }
   }
   return launch_region<KIND, AK, BKC, GUARD>(c, 0, 0, c.m, c.n, stream);
+}
+
+// Modelled time (microseconds) of the form launch_whole would choose for this product with this kind's tile.
+// Where two workgroups share a compute unit a round that is not full does not cost a whole round: a workgroup
+// that has its unit to itself runs at about 1.35 times the shared rate (measured with the 128 x 64 tile: 800 tiles
+// on 512 places take 1.74 rounds, 288 tiles 0.8).
+template <int KIND>
+static double modelled_cost(const GemmCall& c) {
+  typedef Geometry<KIND> G;
+  typedef TileCost<KIND> TC;
+  constexpr int kPerCu = workgroups_per_cu<KIND>();
+  constexpr int kSlots = 256 * kPerCu;
+  const int64_t tiles = ((c.m + G::BM - 1) / G::BM) * ((c.n + G::BN - 1) / G::BN);
+  const double frac = (double)(tiles % kSlots) / kSlots;
+  const double last = frac == 0.0 ? 0.0 : (kPerCu == 1 ? 1.0 : (frac <= 0.5 ? 0.75 : 0.75 + 0.5 * (frac - 0.5)));
+  double best = ((double)(tiles / kSlots) + last) * (TC::t0 + TC::tk * c.k);
+  int k_chunk = 0;
+  double cost = 0.0;
+  if (choose_splits<KIND>(c, &k_chunk, &cost) > 1) best = std::min(best, cost);
+  TailPlan t;
+  if (choose_tail<KIND>(c, &t, &cost)) best = std::min(best, cost);
+  return best;
 }
 
 template <int KIND, bool AK, bool BKC>

@@ -1,0 +1,76 @@
+"""The double-precision kernel exists with two tiles (256 x 128, one workgroup per compute unit; 128 x 64, two
+per unit) and the launcher picks one per product.  Either tile, fixed through EIGAMD_F64_TILE, must give the
+oracle's product at the Netlib tolerance (test ratio < 16, see test_gemm_gpu.py) on whole-tile and ragged extents
+and every operand form; a product that overwrites one of its operands always takes the large tile (the
+triangular solves rely on it), whatever the variable says for the others."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import eigen_amd
+from test_gemm_gpu import ratio
+from test_oracle import RATIO_LIMIT, opmat
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(128, 64, 16), (129, 65, 17), (256, 1024, 256), (1000, 1000, 1000), (300, 200, 1500), (2048, 2048, 256),
+          (64, 64, 8192), (1, 1, 1), (127, 63, 4100)]
+
+
+@pytest.fixture
+def tile_env():
+    old = os.environ.get("EIGAMD_F64_TILE")
+    yield
+    if old is None:
+        os.environ.pop("EIGAMD_F64_TILE", None)
+    else:
+        os.environ["EIGAMD_F64_TILE"] = old
+
+
+@pytest.mark.parametrize("ops", ["NN", "TN", "NT", "TT"])
+def test_both_tiles_vs_oracle(ops, tile_env):
+    import torch
+    from eigen_amd.device import DeviceMatrix, gemm_dev
+    kind = eigen_amd.F64
+    opa, opb = ops
+    for si, (m, n, k) in enumerate(SHAPES):
+        ar, ac = (m, k) if opa == "N" else (k, m)
+        br, bc = (k, n) if opb == "N" else (n, k)
+        pad = 0 if si % 2 == 0 else 3
+        a = DeviceMatrix(ar, ac, kind, ld=ar + pad).fill_uniform(11 + si)
+        b = DeviceMatrix(br, bc, kind, ld=br + pad).fill_uniform(23 + si)
+        ha, hb = a.to_numpy(), b.to_numpy()
+        alpha, beta = [(1.0, 1.0), (0.7, 1.3), (-1.0, 0.0)][si % 3]
+        got = {}
+        for tile in ("1", "2", "0"):
+            os.environ["EIGAMD_F64_TILE"] = tile
+            c = DeviceMatrix(m, n, kind, ld=m + pad).fill_uniform(37 + si)
+            hc = c.to_numpy()
+            gemm_dev(opa, opb, alpha, a, b, beta, c)
+            torch.cuda.synchronize()
+            got[tile] = c.to_numpy()
+        want = np.array(hc, order="F", copy=True)
+        ol.call_f77(ol.oracle_gemm(kind), opa, opb, m, n, k, alpha, np.asfortranarray(ha), ar, np.asfortranarray(hb), br,
+                    beta, want, m)
+        for tile, g in got.items():
+            r = ratio(kind, g, want, alpha, opmat(ha, opa), opmat(hb, opb), beta, hc)
+            assert r < RATIO_LIMIT, (tile, ops, m, n, k, r)
+
+
+def test_in_place_products_keep_the_large_tile(tile_env):
+    """B <- X * B with B 256 rows tall: with the small tile two workgroups per column strip would each read
+    all of B's rows and overwrite half of them."""
+    import torch
+    from eigen_amd.device import DeviceMatrix, gemm_dev
+    kind = eigen_amd.F64
+    os.environ["EIGAMD_F64_TILE"] = "0"
+    for n in (256, 1024, 4096):
+        x = DeviceMatrix(256, 256, kind).fill_uniform(5)
+        b = DeviceMatrix(256, n, kind).fill_uniform(6)
+        want = x.to_numpy() @ b.to_numpy()
+        gemm_dev("N", "N", 1.0, x, b, 0.0, b)
+        torch.cuda.synchronize()
+        err = np.abs(b.to_numpy() - want).max()
+        assert err <= 256 * 4 * np.finfo(np.float64).eps, (n, err)
