@@ -30,8 +30,8 @@
 namespace eigamd {
 
 enum Kind : int { F32 = 0, F64 = 1, C32 = 2, C64 = 3 };
-// A second tile geometry for double, used by the launcher for products of few large tiles (never a caller's kind).
-constexpr int F64S = 4;
+// A second tile geometry for double and for float, used by the launcher for products of few large tiles (never a caller's kind).
+constexpr int F64S = 4, F32S = 5;
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef float f16_t __attribute__((ext_vector_type(16)));
@@ -86,6 +86,10 @@ struct GemmParams {
 #ifndef EIGAMD_F64S_SHAPE
 #define EIGAMD_F64S_SHAPE 2, 2, 4, 2, 16, 2, 1, 1, 2
 #endif
+// float, 128 x 128 tile, two workgroups per CU (the large one is 256 x 256: 64 tiles for a 2048^2 result)
+#ifndef EIGAMD_F32S_SHAPE
+#define EIGAMD_F32S_SHAPE 2, 2, 2, 2, 32, 2, 1, 1, 2
+#endif
 #ifndef EIGAMD_C64_SHAPE
 #define EIGAMD_C64_SHAPE 2, 4, 4, 2, 16, 1, 1, 1, 2
 #endif
@@ -134,6 +138,10 @@ template <> struct Traits<F64> {
 };
 template <> struct Traits<F64S> : Traits<F64> {
   typedef Shape<EIGAMD_F64S_SHAPE> S;
+  static constexpr int WM = S::WM, WN = S::WN, MT = S::MT, NT = S::NT, BK = S::BK;
+};
+template <> struct Traits<F32S> : Traits<F32> {
+  typedef Shape<EIGAMD_F32S_SHAPE> S;
   static constexpr int WM = S::WM, WN = S::WN, MT = S::MT, NT = S::NT, BK = S::BK;
 };
 template <> struct Traits<C32> {

@@ -94,6 +94,7 @@ hipError_t launch_gemm_f64(const GemmCall&, hipStream_t);
 hipError_t launch_gemm_c32(const GemmCall&, hipStream_t);
 hipError_t launch_gemm_c64(const GemmCall&, hipStream_t);
 hipError_t launch_gemm_f64_small(const GemmCall&, hipStream_t);  // the 128 x 64 tile (gemm_inst_f64s.hip)
+hipError_t launch_gemm_f32_small(const GemmCall&, hipStream_t);  // the 128 x 128 tile (gemm_inst_f32s.hip)
 
 template <int KIND, bool AK, bool BKC, bool GUARD>
 static hipError_t launch_region(const GemmCall& c, int64_t r0, int64_t c0, int64_t rows,
@@ -152,6 +153,7 @@ template <> struct TileCost<C64> { static constexpr double t0 = 13.0, tk = 0.467
 template <> struct TileCost<C32> { static constexpr double t0 = 16.0, tk = 0.467; };
 // (per workgroup with two on a compute unit: 128 x 64 x k at about 0.8 of half a CU's rate)
 template <> struct TileCost<F64S> { static constexpr double t0 = 9.0, tk = 0.125; };
+template <> struct TileCost<F32S> { static constexpr double t0 = 12.0, tk = 0.125; };
 
 // A product of few tiles leaves most of the 256 compute units idle while each busy one walks the
 // whole reduction (dgemm 1024^3: 32 tiles, 0.26 ms, 8 TFLOP/s).  Returns how many pieces to cut
@@ -316,6 +318,24 @@ static double modelled_cost(const GemmCall& c) {
   TailPlan t;
   if (choose_tail<KIND>(c, &t, &cost)) best = std::min(best, cost);
   return best;
+}
+
+// Large or small tile for a real kind?  true: the small one.  `fixed`: 1 / 2 from the environment fixes the large /
+// small tile (tests, measurements).  A product that overwrites one of its operands (the triangular solves'
+// B <- inv * B) relies on one large tile covering the operand's whole extent: a workgroup reads all it needs before
+// it stores; memory-side accumulation is tuned for the large tile's long products.
+template <int LARGE, int SMALL>
+static bool small_tile_pays(const GemmCall& c, const char* variable) {
+  const char* e = std::getenv(variable);  // (read per call: tests set it between calls)
+  const int fixed = e ? std::atoi(e) : 0;
+  if (fixed == 1) return false;
+  if (fixed == 2) return true;
+  const bool in_place = c.C == c.A || c.C == c.B;
+  if (c.m <= 0 || c.n <= 0 || c.k <= 0 || c.atomic_c || in_place) return false;
+  typedef Geometry<LARGE> GL;
+  const int64_t large_tiles = ((c.m + GL::BM - 1) / GL::BM) * ((c.n + GL::BN - 1) / GL::BN);
+  if (large_tiles >= 2 * 256) return false;
+  return modelled_cost<SMALL>(c) < 0.95 * modelled_cost<LARGE>(c);
 }
 
 template <int KIND, bool AK, bool BKC>

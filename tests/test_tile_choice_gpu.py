@@ -1,5 +1,6 @@
-"""The double-precision kernel exists with two tiles (256 x 128, one workgroup per compute unit; 128 x 64, two
-per unit) and the launcher picks one per product.  Either tile, fixed through EIGAMD_F64_TILE, must give the
+"""The real kernels exist with two tiles each (double: 256 x 128, one workgroup per compute unit, and 128 x 64, two
+per unit; float: 256 x 256 and 128 x 128) and the launcher picks one per product.  Either tile, fixed through
+EIGAMD_F64_TILE / EIGAMD_F32_TILE, must give the
 oracle's product at the Netlib tolerance (test ratio < 16, see test_gemm_gpu.py) on whole-tile and ragged extents
 and every operand form; a product that overwrites one of its operands always takes the large tile (the
 triangular solves rely on it), whatever the variable says for the others."""
@@ -19,21 +20,25 @@ SHAPES = [(128, 64, 16), (129, 65, 17), (256, 1024, 256), (1000, 1000, 1000), (3
           (64, 64, 8192), (1, 1, 1), (127, 63, 4100)]
 
 
+VARIABLE = {eigen_amd.F64: "EIGAMD_F64_TILE", eigen_amd.F32: "EIGAMD_F32_TILE"}
+
+
 @pytest.fixture
 def tile_env():
-    old = os.environ.get("EIGAMD_F64_TILE")
+    old = {v: os.environ.get(v) for v in VARIABLE.values()}
     yield
-    if old is None:
-        os.environ.pop("EIGAMD_F64_TILE", None)
-    else:
-        os.environ["EIGAMD_F64_TILE"] = old
+    for v, o in old.items():
+        if o is None:
+            os.environ.pop(v, None)
+        else:
+            os.environ[v] = o
 
 
+@pytest.mark.parametrize("kind", [eigen_amd.F64, eigen_amd.F32])
 @pytest.mark.parametrize("ops", ["NN", "TN", "NT", "TT"])
-def test_both_tiles_vs_oracle(ops, tile_env):
+def test_both_tiles_vs_oracle(kind, ops, tile_env):
     import torch
     from eigen_amd.device import DeviceMatrix, gemm_dev
-    kind = eigen_amd.F64
     opa, opb = ops
     for si, (m, n, k) in enumerate(SHAPES):
         ar, ac = (m, k) if opa == "N" else (k, m)
@@ -45,7 +50,7 @@ def test_both_tiles_vs_oracle(ops, tile_env):
         alpha, beta = [(1.0, 1.0), (0.7, 1.3), (-1.0, 0.0)][si % 3]
         got = {}
         for tile in ("1", "2", "0"):
-            os.environ["EIGAMD_F64_TILE"] = tile
+            os.environ[VARIABLE[kind]] = tile
             c = DeviceMatrix(m, n, kind, ld=m + pad).fill_uniform(37 + si)
             hc = c.to_numpy()
             gemm_dev(opa, opb, alpha, a, b, beta, c)
@@ -59,18 +64,19 @@ def test_both_tiles_vs_oracle(ops, tile_env):
             assert r < RATIO_LIMIT, (tile, ops, m, n, k, r)
 
 
-def test_in_place_products_keep_the_large_tile(tile_env):
+@pytest.mark.parametrize("kind", [eigen_amd.F64, eigen_amd.F32])
+def test_in_place_products_keep_the_large_tile(kind, tile_env):
     """B <- X * B with B 256 rows tall: with the small tile two workgroups per column strip would each read
     all of B's rows and overwrite half of them."""
     import torch
     from eigen_amd.device import DeviceMatrix, gemm_dev
-    kind = eigen_amd.F64
-    os.environ["EIGAMD_F64_TILE"] = "0"
+    os.environ[VARIABLE[kind]] = "0"
+    eps = np.finfo(np.float64 if kind == eigen_amd.F64 else np.float32).eps
     for n in (256, 1024, 4096):
         x = DeviceMatrix(256, 256, kind).fill_uniform(5)
         b = DeviceMatrix(256, n, kind).fill_uniform(6)
-        want = x.to_numpy() @ b.to_numpy()
+        want = x.to_numpy().astype(np.float64) @ b.to_numpy().astype(np.float64)
         gemm_dev("N", "N", 1.0, x, b, 0.0, b)
         torch.cuda.synchronize()
         err = np.abs(b.to_numpy() - want).max()
-        assert err <= 256 * 4 * np.finfo(np.float64).eps, (n, err)
+        assert err <= 256 * 4 * eps, (n, err)
