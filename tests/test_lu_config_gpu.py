@@ -147,6 +147,34 @@ def test_host_entry_runs_again_without_the_fused_base_case():
     assert nb1 == nb2 and r1 == r2 == -1
 
 
+def test_host_entry_beside_a_long_product_on_another_stream():
+    """The device shared for real: a queue of large products on another stream fills every compute unit's
+    registers while the factorisation runs.  Whether the one-launch base case still gets its workgroups
+    resident together or gives up and the host entry runs again through the per-column kernels, the
+    result must be the oracle's."""
+    import torch
+    from eigen_amd.device import DeviceMatrix, gemm_dev
+    n = 8192
+    pa = DeviceMatrix(n, n, eigen_amd.F64).fill_uniform(1)
+    pb = DeviceMatrix(n, n, eigen_amd.F64).fill_uniform(2)
+    pc = DeviceMatrix(n, n, eigen_amd.F64).fill_uniform(3)
+    m = 2304
+    a = eigen_amd.fill_uniform_host(np.float64, m, m, 77)
+    a1, a2 = a.copy(order="F"), a.copy(order="F")
+    t1, nb1, r1 = oracle_lu(a1)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(12):  # about 0.2 s of products
+        gemm_dev("N", "N", 1.0, pa, pb, 0.5, pc, stream=side)
+    with env(EIGAMD_LU_SINGLE=0):
+        t2, nb2, r2 = ealu.blocked_lu(a2)
+    busy = not side.query()
+    torch.cuda.synchronize()
+    print("products still running when the factorisation returned:", busy)
+    check_against_oracle(a, a1, t1, a2, t2, exact_pivots=True)
+    assert nb1 == nb2 and r1 == r2 == -1
+
+
 def steep_lower_times_upper(n, rng, dt):
     """A = L U with L unit lower, -0.9 everywhere below the diagonal (inv(L) has entries up to
     0.9 * 1.9^(n-2)), and U a random upper triangle with a dominant diagonal: the diagonal entry
