@@ -1,0 +1,5 @@
+// Instantiates the MFMA GEMM kernels for one scalar kind with its small tile (64 x 64).
+#include "gemm_launch.hpp"
+namespace eigamd {
+hipError_t launch_gemm_c64_small(const GemmCall& c, hipStream_t s) { return launch_gemm<C64S>(c, s); }
+}

@@ -30,8 +30,8 @@
 namespace eigamd {
 
 enum Kind : int { F32 = 0, F64 = 1, C32 = 2, C64 = 3 };
-// A second tile geometry for double and for float, used by the launcher for products of few large tiles (never a caller's kind).
-constexpr int F64S = 4, F32S = 5;
+// A second tile geometry per kind, used by the launcher for products of few large tiles (never a caller's kind).
+constexpr int F64S = 4, F32S = 5, C64S = 6, C32S = 7;
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef float f16_t __attribute__((ext_vector_type(16)));
@@ -89,6 +89,13 @@ struct GemmParams {
 // float, 128 x 128 tile, two workgroups per CU (the large one is 256 x 256: 64 tiles for a 2048^2 result)
 #ifndef EIGAMD_F32S_SHAPE
 #define EIGAMD_F32S_SHAPE 2, 2, 2, 2, 32, 2, 1, 1, 2
+#endif
+// complex double 64 x 64 and complex float 64 x 128, two workgroups per CU
+#ifndef EIGAMD_C64S_SHAPE
+#define EIGAMD_C64S_SHAPE 2, 2, 2, 2, 16, 2, 1, 1, 2
+#endif
+#ifndef EIGAMD_C32S_SHAPE
+#define EIGAMD_C32S_SHAPE 2, 2, 1, 2, 16, 2, 1, 1, 2
 #endif
 #ifndef EIGAMD_C64_SHAPE
 #define EIGAMD_C64_SHAPE 2, 4, 4, 2, 16, 1, 1, 1, 2
@@ -165,6 +172,15 @@ template <> struct Traits<C64> {
   static constexpr int WM = S::WM, WN = S::WN, MT = S::MT, NT = S::NT, BK = S::BK;
   static constexpr int PADX = 0, PADK = 2;
   static constexpr bool kVecWriteK = true;
+};
+
+template <> struct Traits<C64S> : Traits<C64> {
+  typedef Shape<EIGAMD_C64S_SHAPE> S;
+  static constexpr int WM = S::WM, WN = S::WN, MT = S::MT, NT = S::NT, BK = S::BK;
+};
+template <> struct Traits<C32S> : Traits<C32> {
+  typedef Shape<EIGAMD_C32S_SHAPE> S;
+  static constexpr int WM = S::WM, WN = S::WN, MT = S::MT, NT = S::NT, BK = S::BK;
 };
 
 template <int KIND> struct Geometry {

@@ -95,6 +95,8 @@ hipError_t launch_gemm_c32(const GemmCall&, hipStream_t);
 hipError_t launch_gemm_c64(const GemmCall&, hipStream_t);
 hipError_t launch_gemm_f64_small(const GemmCall&, hipStream_t);  // the 128 x 64 tile (gemm_inst_f64s.hip)
 hipError_t launch_gemm_f32_small(const GemmCall&, hipStream_t);  // the 128 x 128 tile (gemm_inst_f32s.hip)
+hipError_t launch_gemm_c64_small(const GemmCall&, hipStream_t);  // 64 x 64 (gemm_inst_c64s.hip)
+hipError_t launch_gemm_c32_small(const GemmCall&, hipStream_t);  // 64 x 128 (gemm_inst_c32s.hip)
 
 template <int KIND, bool AK, bool BKC, bool GUARD>
 static hipError_t launch_region(const GemmCall& c, int64_t r0, int64_t c0, int64_t rows,
@@ -154,6 +156,8 @@ template <> struct TileCost<C32> { static constexpr double t0 = 16.0, tk = 0.467
 // (per workgroup with two on a compute unit: 128 x 64 x k at about 0.8 of half a CU's rate)
 template <> struct TileCost<F64S> { static constexpr double t0 = 9.0, tk = 0.125; };
 template <> struct TileCost<F32S> { static constexpr double t0 = 12.0, tk = 0.125; };
+template <> struct TileCost<C64S> { static constexpr double t0 = 9.0, tk = 0.248; };
+template <> struct TileCost<C32S> { static constexpr double t0 = 10.0, tk = 0.248; };
 
 // A product of few tiles leaves most of the 256 compute units idle while each busy one walks the
 // whole reduction (dgemm 1024^3: 32 tiles, 0.26 ms, 8 TFLOP/s).  Returns how many pieces to cut
@@ -320,7 +324,7 @@ static double modelled_cost(const GemmCall& c) {
   return best;
 }
 
-// Large or small tile for a real kind?  true: the small one.  `fixed`: 1 / 2 from the environment fixes the large /
+// Large or small tile?  true: the small one.  `fixed`: 1 / 2 from the environment fixes the large /
 // small tile (tests, measurements).  A product that overwrites one of its operands (the triangular solves'
 // B <- inv * B) relies on one large tile covering the operand's whole extent: a workgroup reads all it needs before
 // it stores; memory-side accumulation is tuned for the large tile's long products.

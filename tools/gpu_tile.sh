@@ -1,6 +1,6 @@
 #!/bin/bash
 # Products with the large tile (1), the small tile (2) and the launcher's choice (0), batches of 20 launches.
-# DT=f64 (default) or f32.
+# DT=f64 (default), f32, c64 or c32.
 set -o pipefail
 mkdir -p gpurun_out
 {
