@@ -127,6 +127,8 @@ lib.eigamd_last_error.restype = ctypes.c_char_p
 lib.eigamd_last_error.argtypes = []
 lib.eigamd_device_ok.restype = ctypes.c_int
 lib.eigamd_device_ok.argtypes = []
+lib.eigamd_gemm_plan.restype = ctypes.c_int
+lib.eigamd_gemm_plan.argtypes = [ctypes.c_int, _i64, _i64, _i64, ctypes.c_int, _i32p]
 lib.eigamd_tile_shape.restype = None
 lib.eigamd_tile_shape.argtypes = [ctypes.c_int, _i32p, _i32p, _i32p]
 

@@ -1612,6 +1612,26 @@ const char* eigamd_last_error(void) { return g_err.c_str(); }
 
 int eigamd_device_ok(void) { return ensure_device() == EIGAMD_OK ? 1 : 0; }
 
+int eigamd_gemm_plan(int dtype, int64_t m, int64_t n, int64_t k, int c_is_an_operand, int* plan) {
+  if (dtype < 0 || dtype > 3 || m < 1 || n < 1 || k < 1 || !plan) return fail(EIGAMD_ERR_ARG, "invalid plan query");
+  static const char dummy[16] = {0};
+  GemmCall c;
+  c.kind = dtype;
+  c.opa = OP_N; c.opb = OP_N;
+  c.m = m; c.n = n; c.k = k;
+  c.alpha[0] = 1.0; c.alpha[1] = 0.0;
+  c.beta[0] = 1.0; c.beta[1] = 0.0;
+  c.A = dummy; c.B = dummy + 8; c.C = c_is_an_operand ? const_cast<char*>(dummy + 8) : const_cast<char*>(dummy + 4);  // (never dereferenced)
+  c.lda = m; c.ldb = k; c.ldc = m;
+  switch (dtype) {
+    case F32: describe_gemm_f32(c, plan); break;
+    case F64: describe_gemm_f64(c, plan); break;
+    case C32: describe_gemm_c32(c, plan); break;
+    default:  describe_gemm_c64(c, plan); break;
+  }
+  return EIGAMD_OK;
+}
+
 void eigamd_tile_shape(int dtype, int* bm, int* bn, int* bk) {
   switch (dtype) {
     case F32: *bm = Geometry<F32>::BM; *bn = Geometry<F32>::BN; *bk = Geometry<F32>::BK; break;

@@ -8,4 +8,5 @@ namespace eigamd {
 hipError_t launch_gemm_c32(const GemmCall& c, hipStream_t s) {
   return small_tile_pays<C32, C32S>(c, "EIGAMD_C32_TILE") ? launch_gemm_c32_small(c, s) : launch_gemm<C32>(c, s);
 }
+void describe_gemm_c32(const GemmCall& c, int* out) { describe_plan<C32, C32S>(c, "EIGAMD_C32_TILE", out); }
 }

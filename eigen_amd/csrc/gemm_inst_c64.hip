@@ -8,4 +8,5 @@ namespace eigamd {
 hipError_t launch_gemm_c64(const GemmCall& c, hipStream_t s) {
   return small_tile_pays<C64, C64S>(c, "EIGAMD_C64_TILE") ? launch_gemm_c64_small(c, s) : launch_gemm<C64>(c, s);
 }
+void describe_gemm_c64(const GemmCall& c, int* out) { describe_plan<C64, C64S>(c, "EIGAMD_C64_TILE", out); }
 }

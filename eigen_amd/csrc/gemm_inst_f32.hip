@@ -8,4 +8,5 @@ namespace eigamd {
 hipError_t launch_gemm_f32(const GemmCall& c, hipStream_t s) {
   return small_tile_pays<F32, F32S>(c, "EIGAMD_F32_TILE") ? launch_gemm_f32_small(c, s) : launch_gemm<F32>(c, s);
 }
+void describe_gemm_f32(const GemmCall& c, int* out) { describe_plan<F32, F32S>(c, "EIGAMD_F32_TILE", out); }
 }

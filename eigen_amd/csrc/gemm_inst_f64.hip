@@ -9,4 +9,5 @@ namespace eigamd {
 hipError_t launch_gemm_f64(const GemmCall& c, hipStream_t s) {
   return small_tile_pays<F64, F64S>(c, "EIGAMD_F64_TILE") ? launch_gemm_f64_small(c, s) : launch_gemm<F64>(c, s);
 }
+void describe_gemm_f64(const GemmCall& c, int* out) { describe_plan<F64, F64S>(c, "EIGAMD_F64_TILE", out); }
 }

@@ -342,6 +342,34 @@ static bool small_tile_pays(const GemmCall& c, const char* variable) {
   return modelled_cost<SMALL>(c) < 0.95 * modelled_cost<LARGE>(c);
 }
 
+// The decisions launch_gemm_<kind> would take for this product, without launching anything:
+// out[0] = 1 when the small tile is taken; out[1] = pieces the whole reduction is cut into (1: whole);
+// out[2] = pieces of the reduction of the leftover tile lines of the rounds + tail form (0: that form is not used);
+// out[3], out[4] = the tile's extents along m and n.
+template <int KIND>
+static void describe_whole(const GemmCall& c, int* out) {
+  int k_chunk = 0;
+  double split_cost = 0.0, tail_cost = 0.0;
+  TailPlan t;
+  int splits = choose_splits<KIND>(c, &k_chunk, &split_cost);
+  const bool tail = choose_tail<KIND>(c, &t, &tail_cost);
+  if (splits > 1 && tail && tail_cost < split_cost) splits = 1;
+  out[1] = splits;
+  out[2] = (splits <= 1 && tail) ? t.splits : 0;
+  out[3] = Geometry<KIND>::BM;
+  out[4] = Geometry<KIND>::BN;
+}
+template <int LARGE, int SMALL>
+static void describe_plan(const GemmCall& c, const char* variable, int* out) {
+  out[0] = small_tile_pays<LARGE, SMALL>(c, variable) ? 1 : 0;
+  if (out[0]) describe_whole<SMALL>(c, out);
+  else describe_whole<LARGE>(c, out);
+}
+void describe_gemm_f32(const GemmCall&, int*);
+void describe_gemm_f64(const GemmCall&, int*);
+void describe_gemm_c32(const GemmCall&, int*);
+void describe_gemm_c64(const GemmCall&, int*);
+
 template <int KIND, bool AK, bool BKC>
 static hipError_t launch_layout(const GemmCall& c, hipStream_t stream) {
   typedef Geometry<KIND> G;

@@ -345,8 +345,15 @@ int eigamd_trmm_dev(int dtype, int side, int uplo, int op, int diag, int64_t m, 
 /* ---- misc --------------------------------------------------------------------- */
 const char* eigamd_last_error(void);  /* text of the last failure on this thread */
 int eigamd_device_ok(void);           /* 1 if a gfx950 device is usable, else 0 */
-/* Block-tile extents (m, n, k) the kernels use for `dtype`. */
+/* Block-tile extents (m, n, k) the kernels use for `dtype` (the large tile). */
 void eigamd_tile_shape(int dtype, int* bm, int* bn, int* bk);
+/* How eigamd_gemm_dev would launch C += A*B of these extents (column-major, no transposition), decided on the host
+ * alone -- no GPU needed, nothing is launched: plan[0] = 1 when the kind's small tile is taken, plan[1] = pieces the
+ * reduction is cut into for every tile (1: whole), plan[2] = pieces of the reduction of the leftover tile lines when
+ * the product runs as whole rounds of tiles plus a tail (0: not that form), plan[3], plan[4] = the tile's extents
+ * along m and n.  c_is_an_operand: the product overwrites one of its operands (C == B).  No counterpart in the
+ * reference; for tests and for reading a profile. */
+int eigamd_gemm_plan(int dtype, int64_t m, int64_t n, int64_t k, int c_is_an_operand, int* plan);
 
 #ifdef __cplusplus
 }
