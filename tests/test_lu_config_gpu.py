@@ -5,6 +5,8 @@
   own acceptance criterion (test/lu.cpp:168) on sampled rows of P*A - L*U;
 * the same wide outer steps forced at sizes the CPU oracle finishes in seconds
   (EIGAMD_LU_WIDE), against oracle/lu_oracle.c (Eigen/src/LU/PartialPivLU.h:429-498);
+* the trailing update dealt over two streams (EIGAMD_LU_SPLIT_MIN) forced at small sizes: against the oracle and,
+  bit for bit, against the one-stream form;
 * the per-column kernel chain (EIGAMD_LU_FUSED=0, EIGAMD_LU_SINGLE=0), including a column of
   NaNs, and the second attempt of the host entry after a failed one-launch base case.
 """
@@ -91,6 +93,42 @@ def test_forced_wide_outer_steps_vs_oracle(dt, wide, n):
     first_diff = check_against_oracle(a, a1, t1, a2, t2, exact_pivots=dt == np.float64)
     if first_diff is None:
         assert nb1 == nb2
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("split_min,wide,n", [(256, 0, 3072), (512, 512, 3072), (256, 256, 2560), (1024, 1024, 4096)])
+def test_trailing_update_dealt_over_two_streams_vs_oracle(dt, split_min, wide, n):
+    """The bulk of a step's trailing update on two streams (EIGAMD_LU_SPLIT_MIN columns and more remaining; 8192 by
+    default, so only matrices from about 9000 up take it): forced at sizes the oracle finishes in seconds, with the
+    ramp of the first steps, the columns dealt anew as the left part shrinks, and the return to one stream."""
+    a = eigen_amd.fill_uniform_host(dt, n, n, 900 + n + wide)
+    a1, a2 = a.copy(order="F"), a.copy(order="F")
+    t1, nb1, r1 = oracle_lu(a1)
+    knobs = dict(EIGAMD_LU_SPLIT_MIN=split_min)
+    if wide:
+        knobs["EIGAMD_LU_WIDE"] = wide
+    with env(**knobs):
+        t2, nb2, r2 = ealu.blocked_lu(a2)
+    assert r1 == r2 == -1
+    first_diff = check_against_oracle(a, a1, t1, a2, t2, exact_pivots=dt == np.float64)
+    if first_diff is None:
+        assert nb1 == nb2
+
+
+def test_split_and_unsplit_updates_give_the_same_bits():
+    import torch
+    from eigen_amd.device import DeviceMatrix
+    n = 6144
+    out = []
+    for split_min in (0, 256, 2048):
+        with env(EIGAMD_LU_SPLIT_MIN=split_min):
+            a = DeviceMatrix(n, n, eigen_amd.F64).fill_uniform(31)
+            transp, nb, fz = ealu.getrf_dev(a)
+            torch.cuda.synchronize()
+            out.append((a.as_strided().clone(), transp.clone(), nb, fz))
+    for lu, t, nb, fz in out[1:]:
+        assert torch.equal(t, out[0][1]) and nb == out[0][2] and fz == out[0][3]
+        assert torch.equal(lu, out[0][0])
 
 
 def test_wide_steps_equal_narrow_steps_on_device():
