@@ -312,6 +312,34 @@ def variant_measurements():
     return out
 
 
+def mid_size_measurements():
+    """Device-resident square products of a few rounds of tiles, 20 launches back to back after 20 untimed ones
+    (a lone sub-millisecond launch measures the clocks coming up, not the kernel): TFLOP/s."""
+    import torch
+    from eigen_amd.device import DeviceMatrix, gemm_dev
+    out = {}
+    for dtype in ("f64", "f32"):
+        kind = KIND[dtype]
+        for n in (1024, 2048, 2560, 3072, 4096):
+            a = DeviceMatrix(n, n, kind).fill_uniform(1)
+            b = DeviceMatrix(n, n, kind).fill_uniform(2)
+            c = DeviceMatrix(n, n, kind).fill_uniform(3)
+            for _ in range(20):
+                gemm_dev("N", "N", 1.0, a, b, 0.5, c)
+            best = 1e30
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    gemm_dev("N", "N", 1.0, a, b, 0.5, c)
+                e1.record()
+                torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1) / 20)
+            out[f"{BLAS_LETTER[dtype]}gemm_{n}_batch20_tflops"] = round(2.0 * n ** 3 / best / 1e9, 2)
+            del a, b, c
+    return out
+
+
 def measured_traffic(dtype, n):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC
     passes (FETCH_SIZE doubled as gfx950 requires, plus WRITE_SIZE); None when no
@@ -491,6 +519,7 @@ def main():
                 out["extra"].update(trmm_measurement(16384))
                 out["extra"].update(mixed_measurement(8192))
                 out["extra"].update(variant_measurements())
+                out["extra"].update(mid_size_measurements())
                 out["extra"]["sgemm_pct_of_peak"] = round(100 * out["extra"]["sgemm_16384_tflops"] / PEAK_TFLOPS["f32"], 2)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args)
