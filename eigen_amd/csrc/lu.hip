@@ -1248,6 +1248,7 @@ template <typename T> struct Workspace {
   int fused_capacity;   // workgroups of lu_base_fused that are certainly resident together
   BaseCaseRule rule;
   int64_t wide_fixed, wide_t4, wide_t2;  // outer-step width rule of the look-ahead (outer_block)
+  int64_t slice_cols, slice_min;  // the panel stream updates the last slice_cols columns itself while >= slice_min remain (0: off)
   bool ramp;            // the first outer steps of the look-ahead are narrower than the rule's width
   int64_t split_min;    // the bulk update is dealt over two streams while at least this many columns remain (0: never)
   // Scratch of lu_swap_plan / lu_apply_plan and inverses of unit lower triangles (kPlanSpan^2
@@ -1461,6 +1462,7 @@ struct LuStreams {
   hipEvent_t left_done[2] = {nullptr, nullptr};   // update  -> update2: left part of step k (parity k & 1) updated
   hipEvent_t right_done[2] = {nullptr, nullptr};  // update2 -> update, panel: right part of step k updated, scratch of step k free
   hipEvent_t resplit = nullptr;    // update -> update2: everything queued before the columns were dealt anew
+  hipEvent_t slice_done = nullptr; // panel -> update streams: the panel stream's own slice of the trailing update
   hipEvent_t ready = nullptr;      // update -> panel: next panel's columns are current
   hipEvent_t factored = nullptr;   // panel -> update: panel factorised, transpositions known
   hipEvent_t fork = nullptr;       // caller's stream -> update stream
@@ -1523,6 +1525,12 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
   hipStream_t upd2 = (st.update && st.update2 && w.split_min > 0) ? st.update2 : nullptr;
   int64_t mid = -1;                          // first column of the right part; -1: the update is not split
   bool right_recorded[2] = {false, false};   // right_done[parity] has been recorded in this call
+  // While the trailing matrix is large the panel stream's compute units idle for a good part of every step
+  // (the step lasts as long as the trailing product).  They then update the LAST slice_cols columns of the
+  // trailing matrix themselves -- the same chain on those columns, queued behind the step's panel -- and the
+  // update streams leave those columns alone, from the first step until fewer than slice_min columns remain.
+  bool slicing = st.update && w.slice_cols > 0 && size - w.slice_cols >= w.slice_min;
+  bool slice_recorded = false;
   int step = 0;
   // Width of step `i` when `remaining` columns are left.  The first steps ramp up (one panel, two panels,
   // then the rule's width): nothing runs beside the very first panel, so it should be short.
@@ -1578,10 +1586,20 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
     T* A21 = A + (k + bs) + k * ld;
     const int64_t nb = (trows && tsize > 0) ? width_at(step + 1, tsize) : 0;
     // how the columns [lo, size) right of the next step's block are dealt in this step
-    const int64_t lo = k + bs + nb, rest = trows ? tsize - nb : 0;
+    const int64_t lo = k + bs + nb;
+    if (slicing && !(planned && trows && size - w.slice_cols - lo >= w.slice_min)) {
+      // the slice goes back to the update streams
+      slicing = false;
+      if (slice_recorded) {
+        LU_TRY(hipStreamWaitEvent(upd, st.slice_done, 0));
+        if (upd2) LU_TRY(hipStreamWaitEvent(upd2, st.slice_done, 0));
+      }
+    }
+    const int64_t hi = slicing ? size - w.slice_cols : size;  // the update streams' columns end here
+    const int64_t rest = trows ? hi - lo : 0;
     const bool split = upd2 != nullptr && planned && rest >= w.split_min;
     bool dealt_anew = false;
-    if (split ? (mid < 0 || mid - lo < (size - mid) / 3) : mid >= 0) {
+    if (split ? (mid < 0 || mid - lo < (hi - mid) / 3) : mid >= 0) {
       // `upd` is about to touch columns that were the right part's (or stops leaving them alone)
       if (step > 0 && right_recorded[par ^ 1]) LU_TRY(hipStreamWaitEvent(upd, st.right_done[par ^ 1], 0));
       mid = split ? lo + rest / 2 / kPlanSpan * kPlanSpan : -1;
@@ -1608,21 +1626,29 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
     };
     if (!split) {
       // columns to the left (A_0), then the rest of the trailing matrix (A_2)
+      if (slice_recorded) LU_TRY(hipStreamWaitEvent(upd, st.slice_done, 0));  // (the slice's product of the step before reads them)
       LU_TRY(swap_rows(A, k, upd));
-      if (trows && rest > 0) LU_TRY(bulk(lo, size, upd));
+      if (trows && rest > 0) LU_TRY(bulk(lo, hi, upd));
     } else {
       LU_TRY(bulk(lo, mid, upd));
       LU_TRY(hipStreamWaitEvent(upd2, st.factored, 0));
-      LU_TRY(bulk(mid, size, upd2));
-      // The columns to the left: behind the products of the previous step on BOTH streams (they read the
+      LU_TRY(bulk(mid, hi, upd2));
+      // The columns to the left: behind the products of the previous step on ALL streams (they read the
       // previous block's columns, which these transpositions move), and in step order -- hence here.
       if (step > 0) LU_TRY(hipStreamWaitEvent(upd2, st.left_done[par ^ 1], 0));
+      if (slice_recorded) LU_TRY(hipStreamWaitEvent(upd2, st.slice_done, 0));
       LU_TRY(swap_rows(A, k, upd2));
       LU_TRY(hipEventRecord(st.right_done[par], upd2));
       right_recorded[par] = true;
     }
     LU_TRY(hipEventRecord(st.left_done[par], upd));
+    if (slicing) {  // the panel stream's share, behind this step's panel and in front of the next one
+      LU_TRY(bulk(hi, size, pan));
+      LU_TRY(hipEventRecord(st.slice_done, pan));
+      slice_recorded = true;
+    }
   }
+  if (slicing && slice_recorded) LU_TRY(hipStreamWaitEvent(upd, st.slice_done, 0));
   for (int p = 0; p < 2; ++p)
     if (right_recorded[p]) LU_TRY(hipStreamWaitEvent(upd, st.right_done[p], 0));
   // the panel stream has nothing queued after the last `factored` event
@@ -1664,7 +1690,7 @@ void release_lu_streams() {
         *q = nullptr;
       }
     for (hipEvent_t* e : {&st.ready, &st.factored, &st.fork, &st.join, &st.resplit, &st.left_done[0], &st.left_done[1],
-                          &st.right_done[0], &st.right_done[1]})
+                          &st.right_done[0], &st.right_done[1], &st.slice_done})
       if (*e) {
         (void)hipEventDestroy(*e);
         *e = nullptr;
@@ -1709,7 +1735,7 @@ hipError_t make_streams(LuStreams& st, int base_workgroups, int per_cu, int* tot
       }
   }
   if (!st.ready) {
-    for (hipEvent_t* e : {&st.resplit, &st.left_done[0], &st.left_done[1], &st.right_done[0], &st.right_done[1]})
+    for (hipEvent_t* e : {&st.resplit, &st.left_done[0], &st.left_done[1], &st.right_done[0], &st.right_done[1], &st.slice_done})
       LU_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     LU_TRY(hipEventCreateWithFlags(&st.ready, hipEventDisableTiming));
     LU_TRY(hipEventCreateWithFlags(&st.factored, hipEventDisableTiming));
@@ -1782,6 +1808,10 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
     w.wide_fixed = wr.fixed; w.wide_t4 = wr.t4; w.wide_t2 = wr.t2;
     w.split_min = 8192;
     w.ramp = true;
+    w.slice_cols = 1024;
+    w.slice_min = 24576;
+    if (const char* e = getenv("EIGAMD_LU_SLICE")) w.slice_cols = atoll(e) / kPlanSpan * kPlanSpan;
+    if (const char* e = getenv("EIGAMD_LU_SLICE_MIN")) w.slice_min = atoll(e);
     if (const char* e = getenv("EIGAMD_LU_RAMP")) w.ramp = atoi(e) != 0;
     if (const char* e = getenv("EIGAMD_LU_SPLIT_MIN")) w.split_min = atoll(e);
   }

@@ -96,15 +96,17 @@ def test_forced_wide_outer_steps_vs_oracle(dt, wide, n):
 
 
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
-@pytest.mark.parametrize("split_min,wide,n", [(256, 0, 3072), (512, 512, 3072), (256, 256, 2560), (1024, 1024, 4096)])
-def test_trailing_update_dealt_over_two_streams_vs_oracle(dt, split_min, wide, n):
+@pytest.mark.parametrize("split_min,wide,n,slice_cols", [(256, 0, 3072, 0), (512, 512, 3072, 0), (256, 256, 2560, 0), (1024, 1024, 4096, 0),
+                                                         (256, 0, 3072, 256), (0, 512, 4096, 512)])
+def test_trailing_update_dealt_over_two_streams_vs_oracle(dt, split_min, wide, n, slice_cols):
     """The bulk of a step's trailing update on two streams (EIGAMD_LU_SPLIT_MIN columns and more remaining; 8192 by
     default, so only matrices from about 9000 up take it): forced at sizes the oracle finishes in seconds, with the
-    ramp of the first steps, the columns dealt anew as the left part shrinks, and the return to one stream."""
+    ramp of the first steps, the columns dealt anew as the left part shrinks, and the return to one stream; with
+    slice_cols, the panel stream also updates the last columns of the trailing matrix itself (EIGAMD_LU_SLICE)."""
     a = eigen_amd.fill_uniform_host(dt, n, n, 900 + n + wide)
     a1, a2 = a.copy(order="F"), a.copy(order="F")
     t1, nb1, r1 = oracle_lu(a1)
-    knobs = dict(EIGAMD_LU_SPLIT_MIN=split_min)
+    knobs = dict(EIGAMD_LU_SPLIT_MIN=split_min, EIGAMD_LU_SLICE=slice_cols, EIGAMD_LU_SLICE_MIN=1024)
     if wide:
         knobs["EIGAMD_LU_WIDE"] = wide
     with env(**knobs):
@@ -120,8 +122,9 @@ def test_split_and_unsplit_updates_give_the_same_bits():
     from eigen_amd.device import DeviceMatrix
     n = 6144
     out = []
-    for split_min in (0, 256, 2048):
-        with env(EIGAMD_LU_SPLIT_MIN=split_min):
+    # (last: with the panel stream updating the last 512 columns itself while 2048 remain)
+    for split_min, slice_cols in ((0, 0), (256, 0), (2048, 0), (256, 512), (0, 512)):
+        with env(EIGAMD_LU_SPLIT_MIN=split_min, EIGAMD_LU_SLICE=slice_cols, EIGAMD_LU_SLICE_MIN=2048):
             a = DeviceMatrix(n, n, eigen_amd.F64).fill_uniform(31)
             transp, nb, fz = ealu.getrf_dev(a)
             torch.cuda.synchronize()
