@@ -74,6 +74,12 @@ for _name in ("dgetrf_", "sgetrf_", "cgetrf_", "zgetrf_"):
     _f = getattr(lib, _name)
     _f.restype = ctypes.c_int
     _f.argtypes = [_i32p, _i32p, _vp, _i32p, _vp, _i32p]
+for _name in ("sgetrs_", "dgetrs_", "cgetrs_", "zgetrs_"):
+    _f = getattr(lib, _name)
+    _f.restype = ctypes.c_int
+    _f.argtypes = [ctypes.c_char_p, _i32p, _i32p, _vp, _i32p, _vp, _vp, _i32p, _i32p]
+lib.eigamd_getrs_dev.restype = ctypes.c_int
+lib.eigamd_getrs_dev.argtypes = [ctypes.c_int, ctypes.c_int, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp]
 for _name in ("strsm_", "dtrsm_", "ctrsm_", "ztrsm_"):
     _f = getattr(lib, _name)
     _f.restype = ctypes.c_int

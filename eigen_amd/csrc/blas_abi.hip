@@ -1116,6 +1116,92 @@ int zgetrf_(const int* m, const int* n, void* a, const int* lda, int* ipiv, int*
   return f77_getrf(C64, "ZGETRF", m, n, a, lda, ipiv, info);
 }
 
+// ---- ?getrs_ (lapack/lu.cpp:46-89) ---------------------------------------------------
+
+int eigamd_getrs_dev(int dtype, int op, int64_t n, int64_t nrhs, const void* d_lu, int64_t ldlu, const int* d_transp,
+                     void* d_b, int64_t ldb, void* stream) {
+  if (dtype < 0 || dtype > 3) return fail(EIGAMD_ERR_ARG, "dtype out of range");
+  if (op < OP_N || op > OP_C || n < 0 || nrhs < 0 || ldlu < std::max<int64_t>(1, n) || ldb < std::max<int64_t>(1, n) ||
+      n > 0x7fffffff || nrhs > 0x7fffffff)
+    return fail(EIGAMD_ERR_ARG, "invalid getrs arguments");
+  if (n == 0 || nrhs == 0) return EIGAMD_OK;
+  int rc = ensure_device();
+  if (rc != EIGAMD_OK) return rc;
+  HIP_TRY(getrs_device(dtype, op, n, nrhs, d_lu, ldlu, d_transp, d_b, ldb, static_cast<hipStream_t>(stream)));
+  return EIGAMD_OK;
+}
+
+// Host-pointer solve: factors, transpositions (0-based here) and right-hand sides staged in, the
+// m x nrhs window of B copied back.
+static int getrs_host_impl(int dtype, int op, int64_t n, int64_t nrhs, const void* lu, int64_t ldlu, const int* transp0,
+                           void* b, int64_t ldb) {
+  int rc = ensure_device();
+  if (rc != EIGAMD_OK) return rc;
+  const int es = kElemSize[dtype];
+  const int64_t dlda = round_up(n, 16);
+  Staging& st = staging();
+  std::lock_guard<std::mutex> lock(st.mu);
+  if ((rc = st.init()) != EIGAMD_OK) return rc;
+  if ((rc = st.reserve(0, (size_t)dlda * n * es)) != EIGAMD_OK) return rc;
+  if ((rc = st.reserve(1, (size_t)n * sizeof(int) + 64)) != EIGAMD_OK) return rc;
+  if ((rc = st.reserve(2, (size_t)dlda * nrhs * es)) != EIGAMD_OK) return rc;
+  if ((rc = st.upload(st.buf[0], dlda, lu, ldlu, n, n, es)) != EIGAMD_OK) return rc;
+  if ((rc = st.upload(st.buf[2], dlda, b, ldb, n, nrhs, es)) != EIGAMD_OK) return rc;
+  HIP_TRY(hipEventRecord(st.uploaded, st.h2d));
+  HIP_TRY(hipStreamWaitEvent(st.stream, st.uploaded, 0));
+  HIP_TRY(hipMemcpyAsync(st.buf[1], transp0, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st.stream));
+  HIP_TRY(getrs_device(dtype, op, n, nrhs, st.buf[0], dlda, static_cast<const int*>(st.buf[1]), st.buf[2], dlda, st.stream));
+  HIP_TRY(hipEventRecord(st.computed, st.stream));
+  HIP_TRY(hipStreamWaitEvent(st.d2h, st.computed, 0));
+  return st.download(b, ldb, st.buf[2], dlda, n, nrhs, es);
+}
+
+static int f77_getrs(int dtype, const char* name, const char* trans, const int* n, const int* nrhs, const void* a,
+                     const int* lda, int* ipiv, void* b, const int* ldb, int* info) {
+  const int op = op_of(*trans);
+  *info = 0;                                   // lapack/lu.cpp:48-58
+  if (op < 0) *info = -1;
+  else if (*n < 0) *info = -2;
+  else if (*nrhs < 0) *info = -3;
+  else if (*lda < std::max(1, *n)) *info = -5;
+  else if (*ldb < std::max(1, *n)) *info = -8;
+  if (*info != 0) {
+    int e = -*info;
+    return xerbla_(name, &e, 6);
+  }
+  if (*n == 0 || *nrhs == 0) return 0;         // every statement of lu.cpp:65-86 is empty then
+  std::vector<int> transp0(ipiv, ipiv + *n);   // the reference shifts ipiv in place and back (:65-66, :85-86)
+  for (int& t : transp0) --t;
+  for (int i = 0; i < *n; ++i)
+    if (transp0[i] < 0 || transp0[i] >= *n) {
+      std::fprintf(stderr, "eigen_amd %s: ipiv[%d] = %d is not a row of the matrix\n", name, i, ipiv[i]);
+      std::abort();
+    }
+  int rc = getrs_host_impl(dtype, op, *n, *nrhs, a, *lda, transp0.data(), b, *ldb);
+  if (rc != EIGAMD_OK) {
+    std::fprintf(stderr, "eigen_amd %s: %s\n", name, g_err.c_str());
+    std::abort();
+  }
+  return 0;
+}
+
+int sgetrs_(const char* trans, const int* n, const int* nrhs, const float* a, const int* lda, int* ipiv, float* b,
+            const int* ldb, int* info) {
+  return f77_getrs(F32, "SGETRS", trans, n, nrhs, a, lda, ipiv, b, ldb, info);
+}
+int dgetrs_(const char* trans, const int* n, const int* nrhs, const double* a, const int* lda, int* ipiv, double* b,
+            const int* ldb, int* info) {
+  return f77_getrs(F64, "DGETRS", trans, n, nrhs, a, lda, ipiv, b, ldb, info);
+}
+int cgetrs_(const char* trans, const int* n, const int* nrhs, const void* a, const int* lda, int* ipiv, void* b,
+            const int* ldb, int* info) {
+  return f77_getrs(C32, "CGETRS", trans, n, nrhs, a, lda, ipiv, b, ldb, info);
+}
+int zgetrs_(const char* trans, const int* n, const int* nrhs, const void* a, const int* lda, int* ipiv, void* b,
+            const int* ldb, int* info) {
+  return f77_getrs(C64, "ZGETRS", trans, n, nrhs, a, lda, ipiv, b, ldb, info);
+}
+
 // ---- ?trsm_ (blas/level3_impl.h:78-178) ---------------------------------------------
 
 static int side_of(char c) { return (c == 'L' || c == 'l') ? 0 : (c == 'R' || c == 'r') ? 1 : -1; }   // common.h SIDE

@@ -25,6 +25,7 @@
 
 #include "gemm_launch.hpp"
 #include "lu.hpp"
+#include "trsm.hpp"
 
 namespace eigamd {
 
@@ -1917,6 +1918,94 @@ hipError_t trsm_llnu_device(int kind, int64_t bs, int64_t ncols, const void* L, 
   if (kind == F32)
     return trsm_unit_lower2<float>(static_cast<const float*>(L), ldl, static_cast<float*>(B), ldb, bs, ncols, s);
   return hipErrorInvalidValue;
+}
+
+
+// ---- ?getrs: the solve that consumes the factors (lapack/lu.cpp:46-89; PartialPivLU::_solve_impl,
+// Eigen/src/LU/PartialPivLU.h:227-270) --------------------------------------------------------------
+
+namespace {
+
+struct alignas(8) Pair32 { float re, im; };
+struct alignas(16) Pair64 { double re, im; };
+
+// lu_apply_plan for any element type and in either direction: `inverse` undoes the run of
+// transpositions the plan stands for (row src receives what row dst held), which is the run applied
+// in reverse order.
+template <typename T, int COLS>
+__global__ void __launch_bounds__(256) lu_apply_plan_dir(T* __restrict__ A, int64_t ld, int64_t ncols,
+                                                         const SwapPlan* __restrict__ plan, int inverse) {
+  __shared__ T s_val[2 * kPlanSpan * COLS];
+  const int n = plan->count;
+  const int64_t c0 = (int64_t)blockIdx.x * COLS;
+  const int nc = (int)min((int64_t)COLS, ncols - c0);
+  const int* from = inverse ? plan->dst : plan->src;
+  const int* to = inverse ? plan->src : plan->dst;
+  for (int idx = threadIdx.x; idx < n * nc; idx += 256) {
+    const int c = idx / n, j = idx - c * n;
+    s_val[idx] = A[from[j] + (c0 + c) * ld];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < n * nc; idx += 256) {
+    const int c = idx / n, j = idx - c * n;
+    A[to[j] + (c0 + c) * ld] = s_val[idx];
+  }
+}
+
+// The transpositions i <-> transp[i], i in [0, n), on all columns of B: in order (forward) or in
+// reverse order, kPlanSpan of them per pair of launches.
+template <typename T>
+hipError_t permute_rows(T* B, int64_t ldb, int64_t ncols, const int* transp, int64_t n, bool reverse, SwapPlan* plan,
+                        hipStream_t s) {
+  constexpr int kCols = sizeof(T) > 8 ? 4 : 8;
+  const int64_t chunks = (n + kPlanSpan - 1) / kPlanSpan;
+  for (int64_t q = 0; q < chunks; ++q) {
+    const int64_t c = reverse ? chunks - 1 - q : q;
+    const int k0 = (int)(c * kPlanSpan), k1 = (int)std::min<int64_t>(n, (c + 1) * kPlanSpan);
+    LU_TRY(make_plan(transp, k0, k1, plan, s));
+    hipLaunchKernelGGL((lu_apply_plan_dir<T, kCols>), dim3((unsigned)((ncols + kCols - 1) / kCols)), dim3(256), 0, s, B, ldb,
+                       ncols, plan, reverse ? 1 : 0);
+    LU_TRY(hipGetLastError());
+  }
+  return hipSuccess;
+}
+
+}  // namespace
+
+hipError_t getrs_device(int kind, int op, int64_t n, int64_t nrhs, const void* LU, int64_t ldlu, const int* d_transp, void* B,
+                        int64_t ldb, hipStream_t s) {
+  if (kind < 0 || kind > 3 || op < OP_N || op > OP_C) return hipErrorInvalidValue;
+  if (n == 0 || nrhs == 0) return hipSuccess;
+  LuScratch& sc = scratch();
+  std::lock_guard<std::mutex> lock(sc.mu);
+  if (!sc.pub_plan) {
+    LU_TRY(hipMalloc(&sc.pub_plan, sizeof(SwapPlan)));
+    LU_TRY(hipEventCreateWithFlags(&sc.pub_plan_done, hipEventDisableTiming));
+  } else {
+    LU_TRY(hipStreamWaitEvent(s, sc.pub_plan_done, 0));
+  }
+  SwapPlan* plan = static_cast<SwapPlan*>(sc.pub_plan);
+  auto permute = [&](bool reverse) -> hipError_t {
+    switch (kind) {
+      case F32: return permute_rows<float>(static_cast<float*>(B), ldb, nrhs, d_transp, n, reverse, plan, s);
+      case F64: return permute_rows<double>(static_cast<double*>(B), ldb, nrhs, d_transp, n, reverse, plan, s);
+      case C32: return permute_rows<Pair32>(static_cast<Pair32*>(B), ldb, nrhs, d_transp, n, reverse, plan, s);
+      default:  return permute_rows<Pair64>(static_cast<Pair64*>(B), ldb, nrhs, d_transp, n, reverse, plan, s);
+    }
+  };
+  const double one[2] = {1.0, 0.0};
+  if (op == OP_N) {                                  // lu.cpp:67-72: B = P B, then L, then U
+    LU_TRY(permute(false));
+    LU_TRY(hipEventRecord(sc.pub_plan_done, s));
+    LU_TRY(trsm_device(kind, true, /*upper=*/false, OP_N, /*unit=*/true, n, nrhs, one, LU, ldlu, B, ldb, s));
+    LU_TRY(trsm_device(kind, true, /*upper=*/true, OP_N, /*unit=*/false, n, nrhs, one, LU, ldlu, B, ldb, s));
+  } else {                                           // lu.cpp:73-84: op(U), then op(L), then B = P^T B
+    LU_TRY(trsm_device(kind, true, /*upper=*/true, op, /*unit=*/false, n, nrhs, one, LU, ldlu, B, ldb, s));
+    LU_TRY(trsm_device(kind, true, /*upper=*/false, op, /*unit=*/true, n, nrhs, one, LU, ldlu, B, ldb, s));
+    LU_TRY(permute(true));
+    LU_TRY(hipEventRecord(sc.pub_plan_done, s));
+  }
+  return hipSuccess;
 }
 
 }  // namespace eigamd

@@ -37,4 +37,11 @@ hipError_t laswp_device(int kind, void* A, int64_t ld, int64_t ncols, const int*
 hipError_t trsm_llnu_device(int kind, int64_t bs, int64_t ncols, const void* L, int64_t ldl, void* B, int64_t ldb,
                             hipStream_t s);
 
+// op(A) X = B with the factors of getrf_device: LU (n x n, unit lower and upper triangle in place) and
+// its transpositions (device, n ints, 0-based); X overwrites the n x nrhs matrix B.  Any kind; op is an
+// Op of gemm_launch.hpp.  Row exchanges, then two triangular solves (the other way round, with the
+// exchanges undone last, for T and C), as lapack/lu.cpp:67-84 does.  Asynchronous on `s`.
+hipError_t getrs_device(int kind, int op, int64_t n, int64_t nrhs, const void* LU, int64_t ldlu, const int* d_transp, void* B,
+                        int64_t ldb, hipStream_t s);
+
 }  // namespace eigamd

@@ -97,3 +97,28 @@ def trsm_llnu_dev(l, b, stream=None):
     rc = lib.eigamd_trsm_llnu_dev(b.kind, b.rows, b.cols, ctypes.c_void_p(l.ptr), l.ld, ctypes.c_void_p(b.ptr), b.ld,
                                   _stream_ptr(stream))
     _lib.check(rc, "eigamd_trsm_llnu_dev")
+
+
+def getrs(trans, lu, ipiv, b):
+    """LAPACK-style ?getrs_ on Fortran-ordered arrays: op(A) X = B from the factors `lu` and the 1-based
+    `ipiv` of getrf(); X overwrites `b`.  Returns info."""
+    kind = KIND_OF_DTYPE[lu.dtype]
+    fn = {_lib.F32: lib.sgetrs_, _lib.F64: lib.dgetrs_, _lib.C32: lib.cgetrs_, _lib.C64: lib.zgetrs_}[kind]
+    n = lu.shape[0]
+    nrhs = b.shape[1]
+    lda = max(1, lu.strides[1] // lu.itemsize) if n > 1 else max(1, n)
+    ldb = max(1, b.strides[1] // b.itemsize) if nrhs > 1 else max(1, b.shape[0])
+    info = ctypes.c_int(0)
+    ci = lambda v: ctypes.byref(ctypes.c_int(int(v)))
+    fn(ctypes.c_char_p(trans.encode()), ci(n), ci(nrhs), ctypes.c_void_p(lu.ctypes.data), ci(lda),
+       ctypes.c_void_p(ipiv.ctypes.data), ctypes.c_void_p(b.ctypes.data), ci(ldb), ctypes.byref(info))
+    return info.value
+
+
+def getrs_dev(op, lu, transp, b, stream=None):
+    """op(A) X = B on DeviceMatrix operands: `lu` and `transp` (int32 device tensor, 0-based) as getrf_dev
+    leaves them; X overwrites `b`.  Asynchronous on `stream`."""
+    from .device import _stream_ptr
+    rc = lib.eigamd_getrs_dev(lu.kind, op, lu.rows, b.cols, ctypes.c_void_p(lu.ptr), lu.ld, ctypes.c_void_p(transp.data_ptr()),
+                              ctypes.c_void_p(b.ptr), b.ld, _stream_ptr(stream))
+    _lib.check(rc, "eigamd_getrs_dev")

@@ -212,6 +212,31 @@ int eigamd_laswp_dev(int dtype, void* d_a, int64_t lda, int64_t ncols, const int
 int eigamd_trsm_llnu_dev(int dtype, int64_t m, int64_t n, const void* d_l, int64_t ldl, void* d_b, int64_t ldb,
                          void* stream);
 
+/* ---- the solve that consumes the factors -------------------------------------------
+ *
+ * sgetrs_/dgetrs_/cgetrs_/zgetrs_ replace EIGEN_LAPACK_FUNC(getrs) (lapack/lu.cpp:46-89), which is
+ * PartialPivLU::_solve_impl / _solve_impl_transposed (Eigen/src/LU/PartialPivLU.h:227-270) behind the
+ * LAPACK interface: op(A) X = B for the n x n matrix whose ?getrf_ factors are in `a` with the 1-based
+ * ipiv, X overwriting the n x nrhs matrix B.  trans 'N': B = P B, unit-lower solve, upper solve
+ * (lu.cpp:67-72); 'T' / 'C': upper, then unit lower, with the transposed / adjoint triangles, then
+ * B = P^T B (:73-84).  info = -i for a bad argument i through xerbla_ (trans 1, n 2, nrhs 3, lda 5,
+ * ldb 8; :48-58); ipiv is left as it was (the reference shifts it to 0-based and back, :65-66, :85-86).
+ * The row exchanges run 256 at a time, each run as one permutation; the two solves are the ?trsm_ of
+ * this library (all four kinds).
+ *
+ * eigamd_getrs_dev is the same on device memory: d_lu (n x n, ld ldlu) and d_transp (n ints, 0-based, as
+ * eigamd_getrf_dev leaves them), d_b n x nrhs; op is EIGAMD_OP_N / _T / _C.  Asynchronous on `stream`. */
+int sgetrs_(const char* trans, const int* n, const int* nrhs, const float* a, const int* lda, int* ipiv, float* b,
+            const int* ldb, int* info);
+int dgetrs_(const char* trans, const int* n, const int* nrhs, const double* a, const int* lda, int* ipiv, double* b,
+            const int* ldb, int* info);
+int cgetrs_(const char* trans, const int* n, const int* nrhs, const void* a, const int* lda, int* ipiv, void* b,
+            const int* ldb, int* info);   /* a, b: interleaved (re, im) floats */
+int zgetrs_(const char* trans, const int* n, const int* nrhs, const void* a, const int* lda, int* ipiv, void* b,
+            const int* ldb, int* info);   /* a, b: interleaved (re, im) doubles */
+int eigamd_getrs_dev(int dtype, int op, int64_t n, int64_t nrhs, const void* d_lu, int64_t ldlu, const int* d_transp,
+                     void* d_b, int64_t ldb, void* stream);
+
 /* ---- triangular solve with many right-hand sides -------------------------------
  *
  * strsm_/dtrsm_/ctrsm_/ztrsm_ replace EIGEN_BLAS_FUNC(trsm) (blas/level3_impl.h:78-178;

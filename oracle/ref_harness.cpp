@@ -198,6 +198,41 @@ long ref_blocked_lu_z(int64_t rows, int64_t cols, std::complex<double>* a, int64
   return (long)r;
 }
 
+// What EIGEN_LAPACK_FUNC(getrs) runs (lapack/lu.cpp:62-84) on 0-based transpositions: the same three
+// Eigen expressions per value of trans.  op: 0 = N, 1 = T, 2 = C.
+}  // extern "C"
+namespace {
+template <typename S> void getrs_t(int op, int64_t n, int64_t nrhs, S* a, int64_t lda, int* transp0, S* b, int64_t ldb) {
+  typename Views<S>::MMap lu(a, n, n, OuterStride<>(lda));
+  typename Views<S>::MMap B(b, n, nrhs, OuterStride<>(ldb));
+  typedef Map<Transpositions<Dynamic, Dynamic, int> > Pivots;
+  if (op == 0) {
+    B = Pivots(transp0, n) * B;
+    lu.template triangularView<UnitLower>().solveInPlace(B);
+    lu.template triangularView<Upper>().solveInPlace(B);
+  } else if (op == 1) {
+    lu.template triangularView<Upper>().transpose().solveInPlace(B);
+    lu.template triangularView<UnitLower>().transpose().solveInPlace(B);
+    B = Pivots(transp0, n).transpose() * B;
+  } else {
+    lu.template triangularView<Upper>().adjoint().solveInPlace(B);
+    lu.template triangularView<UnitLower>().adjoint().solveInPlace(B);
+    B = Pivots(transp0, n).transpose() * B;
+  }
+}
+}  // namespace
+extern "C" {
+void ref_getrs(int dtype, int op, int64_t n, int64_t nrhs, void* a, int64_t lda, int* transp0, void* b, int64_t ldb) {
+  switch (dtype) {
+    case 0: getrs_t<float>(op, n, nrhs, static_cast<float*>(a), lda, transp0, static_cast<float*>(b), ldb); break;
+    case 1: getrs_t<double>(op, n, nrhs, static_cast<double*>(a), lda, transp0, static_cast<double*>(b), ldb); break;
+    case 2: getrs_t<std::complex<float> >(op, n, nrhs, static_cast<std::complex<float>*>(a), lda, transp0,
+                                          static_cast<std::complex<float>*>(b), ldb); break;
+    default: getrs_t<std::complex<double> >(op, n, nrhs, static_cast<std::complex<double>*>(a), lda, transp0,
+                                            static_cast<std::complex<double>*>(b), ldb); break;
+  }
+}
+
 double ref_bench_lu(int64_t n, int tries) {
   typedef Matrix<double, Dynamic, Dynamic> M;
   M a = M::Random(n, n);

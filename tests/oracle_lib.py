@@ -69,6 +69,10 @@ def load_ref(variant=None):
         f = getattr(lib, name)
         f.restype = ctypes.c_long
         f.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+    if hasattr(lib, "ref_getrs"):
+        lib.ref_getrs.restype = None
+        lib.ref_getrs.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
     lib.variant = variant
     return lib
 
@@ -197,6 +201,18 @@ def run_netlib_chke_trsm(kind, trsm_fn):
 
 def oracle_trsm(kind):
     return getattr(oracle, "oracle_trsm_" + SUFFIX[kind])
+
+
+def oracle_getrs(kind):
+    return getattr(oracle, "oracle_getrs_" + SUFFIX[kind])
+
+
+def call_f77_getrs(fn, trans, n, nrhs, a, lda, ipiv, b, ldb):
+    """Call any function with the F77 ?getrs_ signature on numpy buffers (b is overwritten); returns info."""
+    ci = lambda v: ctypes.byref(ctypes.c_int(int(v)))
+    info = ctypes.c_int(0)
+    fn(ctypes.c_char_p(trans.encode()), ci(n), ci(nrhs), _vp(a), ci(lda), _vp(ipiv), _vp(b), ci(ldb), ctypes.byref(info))
+    return info.value
 
 
 def call_f77_trsm(fn, side, uplo, transa, diag, m, n, alpha, a, lda, b, ldb):

@@ -67,6 +67,23 @@ def test_getrf_argument_errors(name):
     assert info.value == 0
 
 
+@pytest.mark.parametrize("name", ["sgetrs_", "dgetrs_", "cgetrs_", "zgetrs_"])
+def test_getrs_argument_errors(name):
+    a = np.zeros(64, dtype=np.complex128)
+    b = np.ones(64, dtype=np.complex128)
+    ipiv = np.arange(1, 5, dtype=np.int32)
+    i = lambda v: ctypes.byref(ctypes.c_int(v))
+    for (trans, n, nrhs, lda, ldb, code) in [(b"X", 4, 2, 4, 4, 1), (b"N", -1, 2, 4, 4, 2), (b"N", 4, -1, 4, 4, 3),
+                                             (b"T", 4, 2, 3, 4, 5), (b"C", 4, 2, 4, 3, 8)]:      # lapack/lu.cpp:48-58
+        info = ctypes.c_int(0)
+        ol.reset_xerbla()
+        getattr(_lib.lib, name)(ctypes.c_char_p(trans), i(n), i(nrhs), ctypes.c_void_p(a.ctypes.data), i(lda),
+                                ctypes.c_void_p(ipiv.ctypes.data), ctypes.c_void_p(b.ctypes.data), i(ldb), ctypes.byref(info))
+        assert info.value == -code and ol.last_xerbla() == (code, name[:-1].upper())
+        assert np.all(b == 1)
+    ol.reset_xerbla()
+
+
 def test_quick_returns_need_no_device():
     c = np.full((3, 3), 7.0, order="F")
     a = np.ones((3, 3), order="F")
