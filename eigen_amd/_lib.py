@@ -114,6 +114,8 @@ lib.eigamd_symm_dev.restype = ctypes.c_int
 lib.eigamd_symm_dev.argtypes = [ctypes.c_int] * 4 + [_i64, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp]
 lib.eigamd_trmm_dev.restype = ctypes.c_int
 lib.eigamd_trmm_dev.argtypes = [ctypes.c_int] * 5 + [_i64, _i64, _vp, _vp, _i64, _vp, _i64, _vp]
+lib.eigamd_trsm_host.restype = ctypes.c_int
+lib.eigamd_trsm_host.argtypes = [ctypes.c_int] * 5 + [_i64, _i64, _vp, _vp, _i64, _vp, _i64]
 lib.eigamd_trsm_dev.restype = ctypes.c_int
 lib.eigamd_trsm_dev.argtypes = [ctypes.c_int] * 5 + [_i64, _i64, _vp, _vp, _i64, _vp, _i64, _vp]
 _pp = ctypes.POINTER(ctypes.c_void_p)

@@ -1247,6 +1247,18 @@ static int trsm_host_impl(int dtype, int side, int uplo, int op, int diag, int64
   return st.download(b, ldb, st.buf[2], dldb, m, n, es);
 }
 
+int eigamd_trsm_host(int dtype, int side, int uplo, int op, int diag, int64_t m, int64_t n, const void* alpha,
+                     const void* a, int64_t lda, void* b, int64_t ldb) {
+  if (dtype < 0 || dtype > 3) return fail(EIGAMD_ERR_ARG, "dtype out of range");
+  if (side < 0 || side > 1 || uplo < 0 || uplo > 1 || op < OP_N || op > OP_C || diag < 0 || diag > 1 || m < 0 || n < 0 ||
+      lda < std::max<int64_t>(1, side == 0 ? m : n) || ldb < std::max<int64_t>(1, m) || m > 0x7fffffff || n > 0x7fffffff)
+    return fail(EIGAMD_ERR_ARG, "invalid trsm arguments");
+  if (m == 0 || n == 0) return EIGAMD_OK;
+  double al[2];
+  read_scalar(dtype, alpha, al);
+  return trsm_host_impl(dtype, side, uplo, op, diag, m, n, al, a, lda, b, ldb);
+}
+
 static int f77_trsm(int dtype, const char* name, const char* side, const char* uplo, const char* opa, const char* diag,
                     const int* m, const int* n, const void* alpha, const void* a, const int* lda, void* b,
                     const int* ldb) {

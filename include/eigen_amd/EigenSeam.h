@@ -14,7 +14,9 @@
 // column-major operand needs no temporary (EIGAMD_OP_CONJ), and the two forms of
 // general_matrix_matrix_product that Eigen's BLAS binding leaves on the built-in kernel
 // (doc/UsingBlasLapackBackends.dox:59-61) are bound as well: one real and one complex
-// operand, and a destination with a non-unit inner stride (ResInnerStride != 1).
+// operand, and a destination with a non-unit inner stride (ResInnerStride != 1).  The triangular
+// solve with many right-hand sides (triangular_solve_matrix, what TriangularView::solveInPlace and
+// PartialPivLU::solve run) is bound as Eigen/src/Core/products/TriangularSolverMatrix_BLAS.h binds it.
 #ifndef EIGEN_AMD_EIGEN_SEAM_H
 #define EIGEN_AMD_EIGEN_SEAM_H
 
@@ -126,6 +128,51 @@ struct eigamd_product_mixed {
 EIGAMD_PRODUCT_SEAM_MIXED(float)
 EIGAMD_PRODUCT_SEAM_MIXED(double)
 #undef EIGAMD_PRODUCT_SEAM_MIXED
+
+// triangular_solve_matrix with a column-major, unit-inner-stride right-hand side, as
+// Eigen/src/Core/products/TriangularSolverMatrix_BLAS.h:43-101 (left) and :104-160 (right) bind it:
+// a row-major triangle is the transposed column-major one (other triangle, op T, or C when
+// conjugated); a conjugated column-major triangle goes through a conjugated copy, as there.
+// TriangularView::solveInPlace and PartialPivLU::solve reach the device through this.
+template <typename T, typename Index, int Side, int Mode, bool Conjugate, int TriStorageOrder>
+struct eigamd_trsolve {
+  static void run(Index size, Index otherSize, const T* tri, Index triStride, T* other, Index otherIncr, Index otherStride,
+                  level3_blocking<T, T>&) {
+    eigen_assert(otherIncr == 1);
+    EIGEN_ONLY_USED_FOR_DEBUG(otherIncr);
+    const bool lower = (Mode & Lower) == Lower;
+    const bool row_major = TriStorageOrder == RowMajor;
+    const int uplo = (lower != row_major) ? 1 /* EIGAMD_UPLO_LOWER */ : 0 /* EIGAMD_UPLO_UPPER */;
+    const int op = row_major ? (Conjugate ? EIGAMD_OP_C : EIGAMD_OP_T) : EIGAMD_OP_N;
+    const int diag = (Mode & UnitDiag) ? 1 : 0;
+    const int side = Side == OnTheLeft ? 0 : 1;
+    const Index m = Side == OnTheLeft ? size : otherSize, n = Side == OnTheLeft ? otherSize : size;
+    typedef Matrix<T, Dynamic, Dynamic, ColMajor> MatrixTri;
+    MatrixTri conj_copy;
+    const T* a = tri;
+    Index lda = triStride;
+    if (!row_major && Conjugate && NumTraits<T>::IsComplex) {
+      conj_copy = Map<const MatrixTri, 0, OuterStride<> >(tri, size, size, OuterStride<>(triStride)).conjugate();
+      a = conj_copy.data();
+      lda = conj_copy.outerStride();
+    }
+    const T one(1);
+    eigamd_require(eigamd_trsm_host(eigamd_kind<T>::value, side, uplo, op, diag, m, n, &one, a, lda, other, otherStride),
+                   "eigamd_trsm_host");
+  }
+};
+#define EIGAMD_TRSOLVE_SEAM(T)                                                                        \
+  template <typename Index, int Mode, bool Conjugate, int TriStorageOrder>                            \
+  struct triangular_solve_matrix<T, Index, OnTheLeft, Mode, Conjugate, TriStorageOrder, ColMajor, 1>   \
+      : eigamd_trsolve<T, Index, OnTheLeft, Mode, Conjugate, TriStorageOrder> {};                      \
+  template <typename Index, int Mode, bool Conjugate, int TriStorageOrder>                            \
+  struct triangular_solve_matrix<T, Index, OnTheRight, Mode, Conjugate, TriStorageOrder, ColMajor, 1>  \
+      : eigamd_trsolve<T, Index, OnTheRight, Mode, Conjugate, TriStorageOrder> {};
+EIGAMD_TRSOLVE_SEAM(float)
+EIGAMD_TRSOLVE_SEAM(double)
+EIGAMD_TRSOLVE_SEAM(std::complex<float>)
+EIGAMD_TRSOLVE_SEAM(std::complex<double>)
+#undef EIGAMD_TRSOLVE_SEAM
 
 #ifdef EIGEN_PARTIALLU_H
 template <typename T> struct eigamd_lu {

@@ -265,6 +265,10 @@ int ztrsm_(const char* side, const char* uplo, const char* transa, const char* d
            const double* alpha, const double* a, const int* lda, double* b, const int* ldb);
 int eigamd_trsm_dev(int dtype, int side, int uplo, int op, int diag, int64_t m, int64_t n, const void* alpha,
                     const void* d_a, int64_t lda, void* d_b, int64_t ldb, void* stream);
+/* The same on host matrices with 64-bit extents (what triangular_solve_matrix<...,ColMajor,1>::run receives,
+ * Eigen/src/Core/products/TriangularSolverMatrix_BLAS.h:43-101); used by the header-level binding. */
+int eigamd_trsm_host(int dtype, int side, int uplo, int op, int diag, int64_t m, int64_t n, const void* alpha,
+                     const void* a, int64_t lda, void* b, int64_t ldb);
 
 /* ---- symmetric rank-k update ----------------------------------------------------
  *

@@ -79,16 +79,15 @@ template <typename S> static void product_cases(const char* tag, double tol) {
   expect_close(name, big, ref, tol);
 }
 
-#ifdef EIGEN_USE_BLAS
-// The other level-3 routines the reference's headers bind under EIGEN_USE_BLAS
-// (TriangularSolverMatrix_BLAS.h, TriangularMatrixMatrix_BLAS.h, SelfadjointMatrixMatrix_BLAS.h,
-// GeneralMatrixMatrixTriangular_BLAS.h): ?trsm_, ?trmm_, ?symm_ / ?hemm_, ?syrk_ resolve in our library.
-template <typename S> static void structured_cases(const char* tag, double tol) {
+// Triangular solves with many right-hand sides (triangular_solve_matrix): ?trsm_ under EIGEN_USE_BLAS
+// (TriangularSolverMatrix_BLAS.h), eigamd_trsm_host under the header seam; and PartialPivLU::solve, which is
+// a row permutation and two of them (PartialPivLU.h:227-270; what ?getrs_ runs, lapack/lu.cpp:67-84).
+template <typename S> static void solve_cases(const char* tag, double tol) {
   typedef Matrix<S, Dynamic, Dynamic> Mat;
+  typedef Matrix<S, Dynamic, Dynamic, RowMajor> MatR;
   char name[96];
   const int n = 230, m = 120;
-  // off-diagonal entries small against the diagonal (also against a unit diagonal), real
-  // diagonal (a self-adjoint view ignores its imaginary part, a dense copy would not)
+  // off-diagonal entries small against the diagonal (also against a unit diagonal)
   Mat a = Mat::Random(n, n) * S(4.0 / n);
   a.diagonal() = (a.diagonal().real().array() + 2.0).matrix().template cast<S>();
   const Mat b = Mat::Random(n, m), br = Mat::Random(m, n);
@@ -107,6 +106,44 @@ template <typename S> static void structured_cases(const char* tag, double tol) 
   a.adjoint().template triangularView<Lower>().solveInPlace(x);
   std::snprintf(name, sizeof name, "%s A^H tri<Lower>.solveInPlace(B)", tag);
   expect_close(name, Mat(a.adjoint().template triangularView<Lower>()).lazyProduct(x).eval(), b, 50 * tol);
+
+  x = b;
+  a.conjugate().template triangularView<Upper>().solveInPlace(x);
+  std::snprintf(name, sizeof name, "%s conj(A) tri<Upper>.solveInPlace(B)", tag);
+  expect_close(name, Mat(a.conjugate().template triangularView<Upper>()).lazyProduct(x).eval(), b, 50 * tol);
+
+  const MatR ar = a;
+  x = b;
+  ar.template triangularView<UnitLower>().solveInPlace(x);
+  std::snprintf(name, sizeof name, "%s row-major tri<UnitLower>.solveInPlace(B)", tag);
+  expect_close(name, Mat(ar.template triangularView<UnitLower>()).lazyProduct(x).eval(), b, 50 * tol);
+
+  const Mat g = Mat::Random(n, n);
+  PartialPivLU<Mat> plu(g);
+  x = plu.solve(b);
+  std::snprintf(name, sizeof name, "%s PartialPivLU.solve(B)", tag);
+  expect_close(name, g.lazyProduct(x).eval(), b, 2000 * tol);     // test/lu.cpp:180-183 (m2 ~ m1 * m3)
+  x = plu.transpose().solve(b);
+  std::snprintf(name, sizeof name, "%s PartialPivLU.transpose().solve(B)", tag);
+  expect_close(name, g.transpose().lazyProduct(x).eval(), b, 2000 * tol);
+  x = plu.adjoint().solve(b);
+  std::snprintf(name, sizeof name, "%s PartialPivLU.adjoint().solve(B)", tag);
+  expect_close(name, g.adjoint().lazyProduct(x).eval(), b, 2000 * tol);
+}
+
+#ifdef EIGEN_USE_BLAS
+// The other level-3 routines the reference's headers bind under EIGEN_USE_BLAS
+// (TriangularMatrixMatrix_BLAS.h, SelfadjointMatrixMatrix_BLAS.h,
+// GeneralMatrixMatrixTriangular_BLAS.h): ?trmm_, ?symm_ / ?hemm_, ?syrk_ resolve in our library.
+template <typename S> static void structured_cases(const char* tag, double tol) {
+  typedef Matrix<S, Dynamic, Dynamic> Mat;
+  char name[96];
+  const int n = 230, m = 120;
+  // off-diagonal entries small against the diagonal (also against a unit diagonal), real
+  // diagonal (a self-adjoint view ignores its imaginary part, a dense copy would not)
+  Mat a = Mat::Random(n, n) * S(4.0 / n);
+  a.diagonal() = (a.diagonal().real().array() + 2.0).matrix().template cast<S>();
+  const Mat b = Mat::Random(n, m), br = Mat::Random(m, n);
 
   Mat c = a.template triangularView<Upper>() * b;
   std::snprintf(name, sizeof name, "%s C = tri<Upper>(A)*B", tag);
@@ -285,6 +322,10 @@ int main(int argc, char** argv) {
   product_cases<double>("double", 1e-13);
   product_cases<std::complex<float> >("cfloat", 2e-5);
   product_cases<std::complex<double> >("cdouble", 1e-13);
+  solve_cases<float>("float", 2e-5);
+  solve_cases<double>("double", 1e-13);
+  solve_cases<std::complex<float> >("cfloat", 2e-5);
+  solve_cases<std::complex<double> >("cdouble", 1e-13);
 #ifdef EIGEN_USE_BLAS
   structured_cases<float>("float", 2e-5);
   structured_cases<double>("double", 1e-13);
