@@ -193,7 +193,7 @@ struct Staging {
   void* down[2] = {nullptr, nullptr};
   hipEvent_t up_free[2] = {nullptr, nullptr};     // the DMA out of up[i] has finished
   hipEvent_t down_ready[2] = {nullptr, nullptr};  // the DMA into down[i] has finished
-  hipEvent_t uploaded = nullptr, computed = nullptr;
+  hipEvent_t uploaded = nullptr, computed = nullptr, computed2 = nullptr;  // computed / computed2: the two column panels in flight
   int up_next = 0, down_next = 0;
   CopyPool* pool = nullptr;
   int reserve(int i, size_t bytes) {
@@ -218,6 +218,7 @@ struct Staging {
     }
     HIP_TRY(hipEventCreateWithFlags(&uploaded, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&computed, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&computed2, hipEventDisableTiming));
     int nthreads = 8;
     if (const char* e = getenv("EIGAMD_HOST_THREADS")) nthreads = std::max(1, atoi(e));
     pool = new CopyPool(nthreads - 1);
@@ -485,8 +486,7 @@ int gemm_host_impl(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k,
   if (k > 0 && (rc = st.upload(st.buf[0], dlda, a, lda, a_rows, a_cols, es)) != EIGAMD_OK) return rc;
   int64_t panel = round_up(std::max<int64_t>(1, (int64_t)(256u << 20) / std::max<int64_t>(1, m * es)), 256);
   panel = std::min(panel, n);
-  hipEvent_t computed[2] = {st.computed, nullptr};
-  HIP_TRY(hipEventCreateWithFlags(&computed[1], hipEventDisableTiming));
+  hipEvent_t computed[2] = {st.computed, st.computed2};
   auto cpanel = [&](int64_t j0) { return static_cast<char*>(st.buf[2]) + (size_t)j0 * dldc * es; };
   auto fetch = [&](int64_t j0, int slot) -> int {  // panel [j0, j0 + nb) of C back to the caller
     const int64_t nb = std::min(panel, n - j0);
@@ -527,9 +527,7 @@ int gemm_host_impl(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k,
     if (prev >= 0 && (rc = fetch(prev, slot ^ 1)) != EIGAMD_OK) return rc;
     prev = j0;
   }
-  rc = fetch(prev, slot ^ 1);
-  HIP_TRY(hipEventDestroy(computed[1]));
-  return rc;
+  return fetch(prev, slot ^ 1);
 }
 
 int op_of(char ch) {  // blas/common.h:47-50
