@@ -363,7 +363,61 @@ MultiGpuRule multi_gpu_rule() {
 // work is done.  Here the calling thread packs A, B and (unless beta == 0) C into one pinned chunk, ONE
 // copy takes them up, the kernel runs, ONE copy brings C back, one wait.  There is still no CPU product:
 // a 32^3 dgemm_ costs about 50 us where Eigen's own kernel needs 1 us (no fallback, by design).
+// Every call borrows a context of its own (a stream, two pinned chunks, a device buffer) from a per-device
+// pool that grows to the number of calls ever in flight together: host threads that multiply at the same time
+// (Eigen products inside the caller's own parallel region) do not wait for each other, as the reference's
+// ?gemm_ is re-entrant (blas/level3_impl.h:12-76 keeps no state between calls).
 constexpr size_t kSmallProductBytes = (size_t)3 << 20;
+struct SmallContext {
+  hipStream_t stream = nullptr;
+  char* up = nullptr;    // pinned: A, B, C on their way to the device
+  char* down = nullptr;  // pinned: C on its way back
+  char* dev = nullptr;
+};
+constexpr size_t kSmallContextBytes = kSmallProductBytes + 4096;  // (+ the 256-byte alignment of the three images)
+struct SmallPool {
+  std::mutex mu;
+  std::vector<SmallContext*> idle;
+};
+SmallPool& small_pool() {
+  static SmallPool p[kMaxDevices];
+  return p[current_device_slot()];
+}
+int small_context_acquire(SmallContext** out) {
+  SmallPool& pool = small_pool();
+  {
+    std::lock_guard<std::mutex> lock(pool.mu);
+    if (!pool.idle.empty()) {
+      *out = pool.idle.back();
+      pool.idle.pop_back();
+      return EIGAMD_OK;
+    }
+  }
+  SmallContext* c = new SmallContext;
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->up), kSmallContextBytes, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->down), kSmallContextBytes, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->dev), kSmallContextBytes);
+  if (e != hipSuccess) {
+    if (c->dev) (void)hipFree(c->dev);
+    if (c->down) (void)hipHostFree(c->down);
+    if (c->up) (void)hipHostFree(c->up);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return hip_fail(e, "context of a small host-pointer product");
+  }
+  *out = c;
+  return EIGAMD_OK;
+}
+struct SmallContextLease {  // hands the context back when the call ends, whichever way
+  SmallContext* c = nullptr;
+  SmallPool* pool = nullptr;
+  ~SmallContextLease() {
+    if (!c) return;
+    std::lock_guard<std::mutex> lock(pool->mu);
+    pool->idle.push_back(c);
+  }
+};
 int gemm_host_small(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k, const double alpha[2], const void* a,
                     int64_t lda, const void* b, int64_t ldb, const double beta[2], void* c, int64_t ldc) {
   const int es = kElemSize[dtype];
@@ -377,13 +431,13 @@ int gemm_host_small(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k
   const size_t off_b = round_up((int64_t)a_bytes, 256), off_c = off_b + round_up((int64_t)b_bytes, 256);
   const size_t up_bytes = beta_is_zero ? off_c : off_c + c_bytes;
 
-  Staging& st = staging();
-  std::lock_guard<std::mutex> lock(st.mu);
-  int rc = st.init();
+  if (off_c + c_bytes > kSmallContextBytes) return fail(EIGAMD_ERR_ARG, "small host-pointer product beyond its context");
+  SmallContextLease lease;
+  lease.pool = &small_pool();
+  int rc = small_context_acquire(&lease.c);
   if (rc != EIGAMD_OK) return rc;
-  if ((rc = st.reserve(0, off_c + c_bytes)) != EIGAMD_OK) return rc;
-  HIP_TRY(hipEventSynchronize(st.up_free[0]));  // (a large product's last upload out of this chunk)
-  char* pin = static_cast<char*>(st.up[0]);
+  SmallContext& st = *lease.c;
+  char* pin = st.up;
   auto pack = [&](char* dst, int64_t dld, const void* src, int64_t ld, int64_t rows, int64_t cols) {
     const char* sp = static_cast<const char*>(src);
     if (ld == dld && cols > 0) { std::memcpy(dst, sp, ((size_t)ld * (cols - 1) + rows) * es); return; }  // (the last column ends after `rows`)
@@ -394,7 +448,7 @@ int gemm_host_small(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k
     pack(pin + off_b, dldb, b, ldb, b_rows, b_cols);
   }
   if (!beta_is_zero) pack(pin + off_c, dldc, c, ldc, m, n);
-  char* dev = static_cast<char*>(st.buf[0]);
+  char* dev = st.dev;
   if (up_bytes > 0) HIP_TRY(hipMemcpyAsync(dev, pin, up_bytes, hipMemcpyHostToDevice, st.stream));
   GemmCall call;
   call.kind = dtype; call.opa = opa; call.opb = opb;
@@ -406,7 +460,7 @@ int gemm_host_small(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k
   call.C = dev + off_c; call.ldc = dldc;
   call.serial_edges = true;  // (a product this small is one launch anyway; no helper streams)
   HIP_TRY(launch(call, st.stream));
-  char* back = static_cast<char*>(st.down[0]);
+  char* back = st.down;
   HIP_TRY(hipMemcpyAsync(back, dev + off_c, c_bytes, hipMemcpyDeviceToHost, st.stream));
   HIP_TRY(hipStreamSynchronize(st.stream));
   // only the m x n window goes back: rows m..ldc-1 of C keep the caller's bytes
