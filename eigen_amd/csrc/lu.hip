@@ -820,24 +820,46 @@ __global__ void __launch_bounds__(kPlanSpan) lu_swap_plan(const int* __restrict_
   if (t == 0) plan->count = s_count;
 }
 
-// Applies a plan to `ncols` columns starting at A; a workgroup owns kPlanCols columns and
-// stages the moved elements in LDS (every load happens before any store of the workgroup).
-constexpr int kPlanCols = 8;
+// Applies a plan to `ncols` columns starting at A; a workgroup owns kPlanCols columns.  A thread takes one move
+// (two when the plan has more than 256) and carries that row's elements of all the workgroup's columns through
+// registers: up to 2 * kPlanCols independent loads in flight per thread -- every element is a memory line of its
+// own, so the kernel lives on how many lines a compute unit has in flight, and while it holds a compute unit the
+// trailing product of the other update stream cannot use it (1024 exchanges of rows 31 744 long: 1.9 ms with 8
+// columns per workgroup staged through LDS in a loop of dependent index arithmetic).  Every load of the workgroup
+// has completed before any of its stores is issued: a row may be the source of one move and the destination of
+// another.
+constexpr int kPlanCols = 16;
 template <typename T>
 __global__ void __launch_bounds__(256) lu_apply_plan(T* __restrict__ A, int64_t ld, int ncols, const SwapPlan* __restrict__ plan) {
-  __shared__ T s_val[2 * kPlanSpan * kPlanCols];
   const int n = plan->count;
   const int c0 = blockIdx.x * kPlanCols;
   const int nc = min(kPlanCols, ncols - c0);
-  for (int idx = threadIdx.x; idx < n * nc; idx += 256) {
-    const int c = idx / n, j = idx - c * n;
-    s_val[idx] = A[plan->src[j] + (int64_t)(c0 + c) * ld];
+  const int t = threadIdx.x;
+  T* col0 = A + (int64_t)c0 * ld;
+  T v[2][kPlanCols];
+  int src[2], dst[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int j = t + h * 256;
+    src[h] = j < n ? plan->src[j] : -1;
+    dst[h] = j < n ? plan->dst[j] : -1;
   }
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < n * nc; idx += 256) {
-    const int c = idx / n, j = idx - c * n;
-    A[plan->dst[j] + (int64_t)(c0 + c) * ld] = s_val[idx];
-  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    if (src[h] >= 0) {
+#pragma unroll
+      for (int c = 0; c < kPlanCols; ++c)
+        if (c < nc) v[h][c] = col0[src[h] + (int64_t)c * ld];
+    }
+  __builtin_amdgcn_s_waitcnt(0);  // this thread's loads have returned ...
+  __syncthreads();                // ... and so have everybody's
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    if (dst[h] >= 0) {
+#pragma unroll
+      for (int c = 0; c < kPlanCols; ++c)
+        if (c < nc) col0[dst[h] + (int64_t)c * ld] = v[h][c];
+    }
 }
 
 // B <- L^-1 B for a unit lower-triangular jb x jb block L (jb <= JB) and jb x ncols B:
