@@ -324,7 +324,16 @@ hipError_t trsm_device(int kind, bool left, bool upper, int op, bool unit, int64
   if (m <= 0 || n <= 0) return hipSuccess;
   const int es = kElem[kind];
   const int64_t na = left ? m : n;
-  const int64_t kNB = block_extent(kind, left);
+  // A leaf B_j <- inv_j * B_j (or B_j * inv_j) may run in place where one GEMM tile covers the block's extent (a
+  // workgroup then overwrites only what it alone has read), which ties the block to the large tile: 128 columns on
+  // the right side of a double solve, and a launch of few large tiles for every leaf.  Instead the leaf's result
+  // goes to a scratch image and is copied back: any tile may run the leaf (the launcher takes the small one for
+  // these few-tile products) and the blocks are 256 wide on either side for the real kinds.  Measured, in place ->
+  // through the image: dtrsm right side 4096 23.7 -> 32.5 TFLOP/s, 8192 47.3 -> 57.1, 16384 62.8 -> 66.0; left side
+  // 28.9 -> 30.5, 54.9 -> 56.0, 64.8 -> 65.5; strsm 4096 32 -> 40, 8192 78 -> 90; ztrsm 2048 20 -> 24, 4096 44 -> 49.
+  // EIGAMD_TRSM_LEAF_COPY=0: in place, with the block extents that needs (measurements).
+  static const bool leaf_copy = [] { const char* e = getenv("EIGAMD_TRSM_LEAF_COPY"); return !(e && atoi(e) == 0); }();
+  const int64_t kNB = (leaf_copy && (kind == F64 || kind == F32)) ? kLargeNB : block_extent(kind, left);
   const int64_t nblk = (na + kNB - 1) / kNB;
   const char* Ab = static_cast<const char*>(A);
   char* Bb = static_cast<char*>(B);
@@ -335,7 +344,9 @@ hipError_t trsm_device(int kind, bool left, bool upper, int op, bool unit, int64
   InvScratch& sc = inv_scratch();
   std::lock_guard<std::mutex> lock(sc.mu);
   const size_t inv_bytes = (size_t)nblk * kNB * kNB * es;
-  const size_t need = inv_bytes + (size_t)nblk * sizeof(int);
+  const size_t flag_bytes = ((size_t)nblk * sizeof(int) + 255) / 256 * 256;
+  const size_t leaf_bytes = leaf_copy ? (size_t)(left ? n : m) * kNB * es : 0;   // one leaf's result
+  const size_t need = inv_bytes + flag_bytes + leaf_bytes;
   if (!sc.done) TR_TRY(hipEventCreateWithFlags(&sc.done, hipEventDisableTiming));
   if (need > sc.cap) {
     if (sc.buf) {
@@ -445,6 +456,17 @@ hipError_t trsm_device(int kind, bool left, bool upper, int op, bool unit, int64
     if (j1 - j0 == 1) {
       const int64_t p0 = j0 * kNB, pb = std::min<int64_t>(kNB, ext - p0);
       TR_TRY(subst(j0, p0, pb));
+      if (leaf_copy) {  // the product into the scratch image (any tile may run it), then back
+        char* leaf = static_cast<char*>(sc.buf) + inv_bytes + flag_bytes;
+        if (left) {
+          TR_TRY(gemm(kind, op, OP_N, pb, n, pb, 1.0, inv(j0), kNB, b_at(p0, 0), ldb, 0.0, leaf, pb, s));
+          return hipMemcpy2DAsync(b_at(p0, 0), (size_t)ldb * es, leaf, (size_t)pb * es, (size_t)pb * es, (size_t)n,
+                                  hipMemcpyDeviceToDevice, s);
+        }
+        TR_TRY(gemm(kind, OP_N, op, m, pb, pb, 1.0, b_at(0, p0), ldb, inv(j0), kNB, 0.0, leaf, m, s));
+        return hipMemcpy2DAsync(b_at(0, p0), (size_t)ldb * es, leaf, (size_t)m * es, (size_t)m * es, (size_t)pb,
+                                hipMemcpyDeviceToDevice, s);
+      }
       if (left)  // B_j <- op(inv_j) * B_j, in place (one tile row)
         return gemm(kind, op, OP_N, pb, n, pb, 1.0, inv(j0), kNB, b_at(p0, 0), ldb, 0.0, b_at(p0, 0), ldb, s);
       // B_j <- B_j * op(inv_j), in place (one tile column)
