@@ -279,9 +279,34 @@ def lu_measurement(n):
         pa = a0[torch.as_tensor(perm[r0:r0 + block], device="cuda")]
         worst = max(worst, float(torch.linalg.norm(pa - lr @ u) / torch.linalg.norm(pa)))
     eps = 2.0 ** -52
-    return {f"lu_{n}_f64_seconds": round(best, 4), f"lu_{n}_f64_tflops": round(2.0 / 3.0 * n ** 3 / best / 1e12, 2),
-            f"lu_{n}_residual_over_eps_n": round(worst / (eps * n), 4), f"lu_{n}_residual_limit": 8.0,
-            f"lu_{n}_max_abs_l": round(lmax, 6), f"lu_{n}_checks_ok": bool(ok and worst <= 8 * eps * n and lmax <= 1.0)}
+    out = {f"lu_{n}_f64_seconds": round(best, 4), f"lu_{n}_f64_tflops": round(2.0 / 3.0 * n ** 3 / best / 1e12, 2),
+           f"lu_{n}_residual_over_eps_n": round(worst / (eps * n), 4), f"lu_{n}_residual_limit": 8.0,
+           f"lu_{n}_max_abs_l": round(lmax, 6), f"lu_{n}_checks_ok": bool(ok and worst <= 8 * eps * n and lmax <= 1.0)}
+    # the solve that consumes the factors (eigamd_getrs_dev: row exchanges + two triangular solves, 2 n^2 nrhs flop),
+    # checked on sampled rows of A: ||A(rows, :) X - B(rows, :)|| <= 8 eps n ||A(rows, :)|| ||X||
+    del u
+    nrhs = 2048
+    rows = torch.as_tensor(np.random.default_rng(5).choice(n, 64, replace=False), device="cuda")
+    a_rows = a0[rows].clone()
+    del a0
+    b = DeviceMatrix(n, nrhs, eigen_amd.F64)
+    sbest = 1e30
+    for _ in range(2):
+        b.fill_uniform(22)
+        b_rows = b.as_strided()[rows].clone()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ealu.getrs_dev(eigen_amd.OP_N, a, transp, b)
+        e1.record()
+        torch.cuda.synchronize()
+        sbest = min(sbest, e0.elapsed_time(e1) * 1e-3)
+    x = b.as_strided()
+    res = float(torch.linalg.norm(a_rows @ x - b_rows) / (torch.linalg.norm(a_rows) * torch.linalg.norm(x)))
+    out.update({f"lu_solve_{n}x{nrhs}_f64_seconds": round(sbest, 4),
+                f"lu_solve_{n}x{nrhs}_f64_tflops": round(2.0 * n * n * nrhs / sbest / 1e12, 2),
+                f"lu_solve_{n}_backward_error_over_eps_n": round(res / (eps * n), 4),
+                f"lu_solve_{n}_checks_ok": bool(res <= 8 * eps * n)})
+    return out
 
 
 def variant_measurements():
