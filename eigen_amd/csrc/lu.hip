@@ -1488,6 +1488,7 @@ struct LuStreams {
   hipEvent_t slice_done = nullptr; // panel -> update streams: the panel stream's own slice of the trailing update
   hipEvent_t ready = nullptr;      // update -> panel: next panel's columns are current
   hipEvent_t factored = nullptr;   // panel -> update: panel factorised, transpositions known
+  hipEvent_t inverted = nullptr;   // panel -> update: the inverted triangles of the step are there
   hipEvent_t fork = nullptr;       // caller's stream -> update stream
   hipEvent_t join = nullptr;       // update stream -> caller's stream
   int panel_cus = 0;               // CUs set aside for the panel stream (0: none, streams share the chip)
@@ -1582,12 +1583,16 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
     if (planned)
       for (int i = 0; i < nsub; ++i)
         LU_TRY(make_plan(transp, (int)(k + sub_begin(i)), (int)(k + sub_begin(i) + sub_size(i)), plan[i], pan));
+    // The update streams start on the row exchanges as soon as the plans are there; the inverted triangles,
+    // which only the solves need, are worked out beside them (0.16 ms per 256-wide piece that used to sit between
+    // the panel and everything that follows it).
+    LU_TRY(hipEventRecord(st.factored, pan));
+    LU_TRY(hipStreamWaitEvent(upd, st.factored, 0));
     if (trows > 0)
       for (int i = 0; i < nsub; ++i)
         if (inverse_applies<T>(sub_size(i)))
           LU_TRY(make_inverse<T>(A + (k + sub_begin(i)) * (ld + 1), ld, sub_size(i), linv[i], linv_flag[i], w.linv_max[par * kMaxSub + i], w.inverse_limit, pan));
-    LU_TRY(hipEventRecord(st.factored, pan));
-    LU_TRY(hipStreamWaitEvent(upd, st.factored, 0));
+    LU_TRY(hipEventRecord(st.inverted, pan));
     // the step's transpositions, in order, on `ncols` columns
     auto swap_rows = [&](T* cols, int64_t ncols, hipStream_t q) -> hipError_t {
       if (!planned) return laswp<T>(cols, ld, ncols, transp, (int)k, (int)(k + bs), nullptr, q);
@@ -1597,6 +1602,7 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
     // A12 <- L^-1 A12 with L the unit lower triangle of the step's bs x bs block, piece by piece:
     // the piece's own triangle (inverted where that applies), then the rows of the later pieces.
     auto solve = [&](T* A12, int64_t ncols, hipStream_t q) -> hipError_t {
+      if (q != pan) LU_TRY(hipStreamWaitEvent(q, st.inverted, 0));
       for (int i = 0; i < nsub; ++i) {
         const int64_t o = sub_begin(i), sb = sub_size(i);
         const T* L = A + (k + o) * (ld + 1);
@@ -1712,7 +1718,7 @@ void release_lu_streams() {
         (void)hipStreamDestroy(*q);
         *q = nullptr;
       }
-    for (hipEvent_t* e : {&st.ready, &st.factored, &st.fork, &st.join, &st.resplit, &st.left_done[0], &st.left_done[1],
+    for (hipEvent_t* e : {&st.ready, &st.factored, &st.inverted, &st.fork, &st.join, &st.resplit, &st.left_done[0], &st.left_done[1],
                           &st.right_done[0], &st.right_done[1], &st.slice_done})
       if (*e) {
         (void)hipEventDestroy(*e);
@@ -1762,6 +1768,7 @@ hipError_t make_streams(LuStreams& st, int base_workgroups, int per_cu, int* tot
       LU_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     LU_TRY(hipEventCreateWithFlags(&st.ready, hipEventDisableTiming));
     LU_TRY(hipEventCreateWithFlags(&st.factored, hipEventDisableTiming));
+    LU_TRY(hipEventCreateWithFlags(&st.inverted, hipEventDisableTiming));
     LU_TRY(hipEventCreateWithFlags(&st.fork, hipEventDisableTiming));
     LU_TRY(hipEventCreateWithFlags(&st.join, hipEventDisableTiming));
   }
