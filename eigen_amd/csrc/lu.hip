@@ -1040,16 +1040,53 @@ __global__ void __launch_bounds__(256) lu_trtri_merge(const T* __restrict__ L, i
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[q][e] = (T)0;
   const int klimit = (ib + 1) * kMergeRows;
-  for (int k0 = 0; k0 < klimit; k0 += kMergeK) {
-    for (int idx = threadIdx.x; idx < kMergeK * h; idx += 256) {
+  // The k-chunks of both phases go global memory -> registers -> LDS, one chunk ahead: the loads of chunk c + 1 are
+  // in flight while chunk c is multiplied (the chain of 16 to 24 chunks was a chain of as many trips to memory).
+  constexpr int kBPer = kMergeK * kMergeMaxH / 256, kAPer = kMergeRows * kMergeK / 256;
+  T rb[kBPer], ra[kAPer];
+  auto fetch0 = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < kBPer; ++u) {
+      const int idx = threadIdx.x + u * 256;
       const int kk = idx % kMergeK, j = idx / kMergeK;
-      s_b[kk][j] = L[(base + h + k0 + kk) + (int64_t)(base + j) * ldl];
+      rb[u] = idx < kMergeK * h ? L[(base + h + k0 + kk) + (int64_t)(base + j) * ldl] : (T)0;
     }
-    for (int idx = threadIdx.x; idx < kMergeRows * kMergeK; idx += 256) {
+#pragma unroll
+    for (int u = 0; u < kAPer; ++u) {
+      const int idx = threadIdx.x + u * 256;
       const int i = idx % kMergeRows, kk = idx / kMergeRows;
-      s_a[i][kk] = X[(r0 + i) + (int64_t)(base + h + k0 + kk) * bs];
+      ra[u] = X[(r0 + i) + (int64_t)(base + h + k0 + kk) * bs];
     }
+  };
+  auto fetch1 = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < kBPer; ++u) {
+      const int idx = threadIdx.x + u * 256;
+      const int kk = idx % kMergeK, j = idx / kMergeK;
+      rb[u] = idx < kMergeK * h ? X[(base + k0 + kk) + (int64_t)(base + j) * bs] : (T)0;
+    }
+  };
+  auto put_b = [&]() {
+#pragma unroll
+    for (int u = 0; u < kBPer; ++u) {
+      const int idx = threadIdx.x + u * 256;
+      if (idx < kMergeK * h) s_b[idx % kMergeK][idx / kMergeK] = rb[u];
+    }
+  };
+  auto put_a = [&]() {
+#pragma unroll
+    for (int u = 0; u < kAPer; ++u) {
+      const int idx = threadIdx.x + u * 256;
+      s_a[idx % kMergeRows][idx / kMergeRows] = ra[u];
+    }
+  };
+  fetch0(0);
+  for (int k0 = 0; k0 < klimit; k0 += kMergeK) {
+    put_b();
+    put_a();
     __syncthreads();
+    if (k0 + kMergeK < klimit) fetch0(k0 + kMergeK);
+    else fetch1(0);   // the first chunk of phase 1 (inv(A): finished by an earlier launch)
 #pragma unroll
     for (int kk = 0; kk < kMergeK; ++kk) {
       const T a0 = s_a[ti][kk], a1 = s_a[ti + 16][kk];
@@ -1079,11 +1116,9 @@ __global__ void __launch_bounds__(256) lu_trtri_merge(const T* __restrict__ L, i
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[q][e] = (T)0;
   for (int k0 = 0; k0 < h; k0 += kMergeK) {
-    for (int idx = threadIdx.x; idx < kMergeK * h; idx += 256) {
-      const int kk = idx % kMergeK, j = idx / kMergeK;
-      s_b[kk][j] = X[(base + k0 + kk) + (int64_t)(base + j) * bs];
-    }
+    put_b();
     __syncthreads();
+    if (k0 + kMergeK < h) fetch1(k0 + kMergeK);
 #pragma unroll
     for (int kk = 0; kk < kMergeK; ++kk) {
       const T a0 = s_t[ti][k0 + kk], a1 = s_t[ti + 16][k0 + kk];

@@ -103,6 +103,14 @@ def test_64bit_entry_rejects_bad_arguments():
     assert rc == _lib.ERR_ARG and b"#10" in _lib.lib.eigamd_last_error()
     rc = _lib.lib.eigamd_gemm_dev(7, 0, 0, 2, 2, 2, p(one), p(x), 2, p(x), 2, p(one), p(x), 2, None)
     assert rc == _lib.ERR_ARG
+    # the 64-bit solve entries: side / uplo / op / diag out of range, leading dimensions too small
+    assert _lib.lib.eigamd_trsm_host(_lib.F64, 2, 0, 0, 0, 2, 2, p(one), p(x), 2, p(x), 2) == _lib.ERR_ARG
+    assert _lib.lib.eigamd_trsm_host(_lib.F64, 0, 0, 3, 0, 2, 2, p(one), p(x), 2, p(x), 2) == _lib.ERR_ARG
+    assert _lib.lib.eigamd_trsm_host(_lib.F64, 0, 0, 0, 0, 2, 2, p(one), p(x), 1, p(x), 2) == _lib.ERR_ARG
+    assert _lib.lib.eigamd_trsm_host(_lib.F64, 0, 0, 0, 0, 0, 2, p(one), p(x), 1, p(x), 1) == _lib.OK   # m == 0: nothing to do
+    assert _lib.lib.eigamd_getrs_dev(_lib.F64, 5, 2, 2, p(x), 2, None, p(x), 2, None) == _lib.ERR_ARG
+    assert _lib.lib.eigamd_getrs_dev(_lib.F64, 0, 2, 2, p(x), 1, None, p(x), 2, None) == _lib.ERR_ARG
+    assert _lib.lib.eigamd_getrs_dev(_lib.F64, 0, 0, 2, p(x), 1, None, p(x), 1, None) == _lib.OK        # n == 0
 
 
 @pytest.mark.skipif(_lib.lib.eigamd_device_ok() == 1, reason="a GPU is present")

@@ -113,3 +113,27 @@ def test_large_solve_residual(kind, side, uplo, trans, diag):
         g = abs1(x[rows]) @ abs1(topd) + abs(alpha) * abs1(b[rows])
     ratio = (abs1(res) / (ol.EPS[kind] * g)).max()
     assert ratio < np.sqrt(na), ratio
+
+
+@pytest.mark.parametrize("kind", range(4))
+def test_host_entry_64bit_vs_oracle(kind):
+    """eigamd_trsm_host (what the header seam's triangular_solve_matrix calls): host operands with padded
+    leading dimensions, a few forms on both sides, against the oracle; padding rows of B untouched."""
+    import ctypes
+    dt = ol.DTYPES[kind]
+    alpha = np.array([(0.7 - 0.9j) if kind >= 2 else 0.7], dtype=dt)
+    SIDE, UPLO, OP, DIAG = {"L": 0, "R": 1}, {"U": 0, "L": 1}, {"N": 0, "T": 1, "C": 2}, {"N": 0, "U": 1}
+    vp = lambda x: ctypes.c_void_p(x.ctypes.data)
+    for seed, (side, uplo, trans, diag, m, n) in enumerate([("L", "L", "N", "U", 300, 170), ("L", "U", "C", "N", 513, 40),
+                                                            ("R", "U", "N", "N", 170, 300), ("R", "L", "T", "U", 77, 600)]):
+        a, b = ol.trsm_operands(kind, side, uplo, diag, m, n, 900 + seed, pad=2)
+        na = a.shape[0]
+        bbuf = np.asfortranarray(np.full((m + 2, n), -1.0e10, dtype=dt))
+        bbuf[:m] = b
+        want = bbuf.copy(order="F")
+        ol.call_f77_trsm(ol.oracle_trsm(kind), side, uplo, trans, diag, m, n, alpha[0], a, na + 2, want, m + 2)
+        rc = _lib.lib.eigamd_trsm_host(kind, SIDE[side], UPLO[uplo], OP[trans], DIAG[diag], m, n, vp(alpha), vp(a), na + 2,
+                                       vp(bbuf), m + 2)
+        _lib.check(rc, "eigamd_trsm_host")
+        assert np.array_equal(bbuf[m:], want[m:]), "padding rows of B were written"
+        assert np.abs(bbuf[:m] - want[:m]).max() <= 64 * ol.EPS[kind] * na * np.abs(want[:m]).max(), (side, uplo, trans, diag)
