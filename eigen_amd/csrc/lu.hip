@@ -765,6 +765,161 @@ __global__ void __launch_bounds__(256) lu_rank_update(const T* __restrict__ A, c
   }
 }
 
+// lu_rowops and lu_rank_update of one 16-column block in ONE launch (a launch of the panel's chain costs 10 us and
+// more whatever it does; at 8192 rows the two were 14 + 13 us of a block's 95).  What the row operations change are
+// the block's "special" rows -- its jb top rows and the rows its transpositions name -- in the columns right of the
+// block; what the rank update needs of them is U12, the top rows after exchanges and forward substitution.  Every
+// workgroup of a column block reads the special rows of its 32 columns as they are, works out U12 and the exchanged
+// rows in LDS (redundantly: 32 rows x 32 columns), and updates its own 256 rows, skipping special ones.  Nobody
+// writes a special row while anybody may still read it: a workgroup counts itself in once its reads have landed in
+// LDS, and the workgroup that completes the count of its column block writes that block's special rows at the end --
+// U12 into the top rows, and "old top row - L(p, :) U12" into every named row p -- and puts the counter back to
+// zero.  No workgroup waits for another.  The columns left of the block inside the panel only exchange rows: extra
+// workgroups at the end of the grid, one thread per column.  Same operations per element, in the same order, as
+// lu_rowops followed by lu_rank_update.  Row and column arguments are absolute (`base` is the matrix).
+template <typename T>
+__global__ void __launch_bounds__(256) lu_rowops_rank_update(T* __restrict__ base, int64_t ld, const int* __restrict__ transp,
+                                                            int k0, int jb, int cL, int cR, int nright, int cLeft0, int nleft,
+                                                            int trows, int nrb, int ncb, int* __restrict__ counters) {
+  __shared__ T s_rows[2 * kMaxBase][kRankCols + 1];  // [0, 16): the top rows, then U12; [16, 32): the rows named by the transpositions
+  __shared__ T s_l[kMaxBase * kMaxBase];
+  __shared__ int s_p[kMaxBase];
+  __shared__ int s_slot[kMaxBase];   // where row s_p[i] lives in s_rows
+  __shared__ int s_last;
+  const int t = threadIdx.x;
+  if (t < kMaxBase) s_p[t] = t < jb ? transp[k0 + t] : -1;
+  for (int i = t; i < jb * jb; i += 256) s_l[(i % jb) + (i / jb) * kMaxBase] = base[(k0 + i % jb) + (int64_t)(cL + i / jb) * ld];
+  __syncthreads();
+  const int b = blockIdx.x;
+  if (b >= nrb * ncb) {  // the columns to the left: exchanges only
+    const int c = (b - nrb * ncb) * 256 + t;
+    if (c < nleft) {
+      T* col = base + (int64_t)(cLeft0 + c) * ld;
+      for (int i = 0; i < jb; ++i) {
+        const int p = s_p[i];
+        if (p != k0 + i) {
+          const T v = col[k0 + i];
+          col[k0 + i] = col[p];
+          col[p] = v;
+        }
+      }
+    }
+    return;
+  }
+  const int rb = b % nrb, cb = b / nrb;
+  const int c0 = cb * kRankCols;
+  const int nc = min(kRankCols, nright - c0);
+  if (t < kMaxBase) {
+    int slot = -1;
+    if (t < jb) {
+      const int p = s_p[t];
+      if (p < k0 + jb) {
+        slot = p - k0;            // one of the top rows
+      } else {
+        slot = kMaxBase + t;      // a row below them: the slot of the first transposition that names it
+        for (int j = t - 1; j >= 0; --j)
+          if (s_p[j] == p) slot = kMaxBase + j;
+      }
+    }
+    s_slot[t] = slot;
+  }
+  __syncthreads();
+  T* colsR = base + (int64_t)(cR + c0) * ld;
+  for (int idx = t; idx < 2 * kMaxBase * kRankCols; idx += 256) {
+    const int half = idx / (kMaxBase * kRankCols), e = idx % (kMaxBase * kRankCols);
+    const int i = e % kMaxBase, j = e / kMaxBase;   // consecutive threads: consecutive top rows of one column
+    T v = (T)0;
+    if (i < jb && j < nc) {
+      if (half == 0) v = colsR[(k0 + i) + (int64_t)j * ld];
+      else if (s_slot[i] == kMaxBase + i) v = colsR[s_p[i] + (int64_t)j * ld];
+    }
+    s_rows[half * kMaxBase + i][j] = v;
+  }
+  __syncthreads();
+  // every special row this workgroup reads is in LDS now
+  if (t == 0) {
+    const int arrived = __hip_atomic_fetch_add(counters + cb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = arrived == nrb - 1;
+    if (last) __hip_atomic_store(counters + cb, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = last;
+  }
+  if (t < kRankCols) {  // one thread per column: the exchanges in order, then the forward substitution (as lu_rowops)
+    for (int i = 0; i < jb; ++i) {
+      if (s_p[i] != k0 + i) {
+        const int sl = s_slot[i];
+        const T v = s_rows[i][t];
+        s_rows[i][t] = s_rows[sl][t];
+        s_rows[sl][t] = v;
+      }
+    }
+    T x[kMaxBase];
+#pragma unroll
+    for (int i = 0; i < kMaxBase; ++i) x[i] = i < jb ? s_rows[i][t] : (T)0;
+#pragma unroll
+    for (int i = 0; i < kMaxBase; ++i) {
+      if (i < jb) {
+#pragma unroll
+        for (int rr = i + 1; rr < kMaxBase; ++rr)
+          if (rr < jb) x[rr] -= s_l[rr + i * kMaxBase] * x[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kMaxBase; ++i)
+      if (i < jb) s_rows[i][t] = x[i];
+  }
+  __syncthreads();
+  const int lr = rb * 256 + t;        // row of the trailing part
+  const int r = k0 + jb + lr;         // the same, absolute
+  bool plain = lr < trows;
+  if (plain)
+    for (int i = 0; i < jb; ++i)
+      if (s_p[i] == r) plain = false;  // a special row: the workgroup that completes the count writes it
+  if (plain) {
+    T a[kMaxBase];
+#pragma unroll
+    for (int k = 0; k < kMaxBase; ++k) a[k] = k < jb ? base[r + (int64_t)(cL + k) * ld] : (T)0;
+    T* Cr = colsR + r;
+    int j0 = 0;
+    constexpr int kGroup = EIGAMD_LU_RANK_GROUP;
+    for (; j0 + kGroup <= nc; j0 += kGroup) {
+      T c[kGroup];
+#pragma unroll
+      for (int u = 0; u < kGroup; ++u) c[u] = Cr[(int64_t)(j0 + u) * ld];
+#pragma unroll
+      for (int u = 0; u < kGroup; ++u) {
+        T acc = (T)0;
+#pragma unroll
+        for (int k = 0; k < kMaxBase; ++k) acc += a[k] * s_rows[k][j0 + u];
+        c[u] -= acc;
+      }
+#pragma unroll
+      for (int u = 0; u < kGroup; ++u) Cr[(int64_t)(j0 + u) * ld] = c[u];
+    }
+    for (; j0 < nc; ++j0) {
+      T acc = (T)0;
+#pragma unroll
+      for (int k = 0; k < kMaxBase; ++k) acc += a[k] * s_rows[k][j0];
+      Cr[(int64_t)j0 * ld] -= acc;
+    }
+  }
+  if (s_last) {  // every workgroup of this column block has read the special rows: they may be written now
+    for (int e = t; e < kMaxBase * kRankCols; e += 256) {
+      const int i = e % kMaxBase, j = e / kMaxBase;
+      if (i < jb && j < nc) colsR[(k0 + i) + (int64_t)j * ld] = s_rows[i][j];
+    }
+    for (int e = t; e < kMaxBase * kRankCols; e += 256) {
+      const int i = e % kMaxBase, j = e / kMaxBase;
+      if (i < jb && j < nc && s_slot[i] == kMaxBase + i) {
+        const int p = s_p[i];
+        T acc = (T)0;
+#pragma unroll
+        for (int k = 0; k < kMaxBase; ++k) acc += (k < jb ? base[p + (int64_t)(cL + k) * ld] : (T)0) * s_rows[k][j];
+        colsR[p + (int64_t)j * ld] = s_rows[kMaxBase + i][j] - acc;
+      }
+    }
+  }
+}
+
 // ---- many transpositions at once ----------------------------------------------------
 //
 // A run of transpositions i <-> transp[i], i in [k0, k1), k1 - k0 <= kPlanSpan, applied in
@@ -1317,6 +1472,8 @@ template <typename T> struct Workspace {
   int* linv_flag[2 * kMaxSub + 1];  // set by lu_inverse_finish: solve by substitution, linv holds the identity
   unsigned long long* linv_max[2 * kMaxSub + 1];  // max|inv(L)| as the inversion kernels noted it (zero between uses)
   double inverse_limit;
+  int* rank_count;      // per column block of lu_rowops_rank_update (zero between launches), or null: two launches
+  int64_t rank_fused_max;  // ... used for panels of at most this many rows below the block (taller: two launches)
 };
 constexpr int kOwnScratch = 2 * kMaxSub;
 
@@ -1465,6 +1622,15 @@ hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows
       // Narrow blocks (inside a panel): the transpositions on both sides (A_0 :479-483, A_2
       // :488-489) and the triangular solve (:492) in one launch, then the rank-bs update (:494).
       const int64_t nright = trows ? tsize : 0;
+      if (w.rank_count && trows > 0 && trows <= w.rank_fused_max && tsize > 0) {   // row operations and rank update in one launch
+        const int nrb = (int)((trows + 255) / 256), ncb = (int)((tsize + kRankCols - 1) / kRankCols);
+        const int nleft_wg = (int)((k + 255) / 256);
+        hipLaunchKernelGGL(lu_rowops_rank_update<T>, dim3((unsigned)(nrb * ncb + nleft_wg)), dim3(256), 0, s, base, ld, transp,
+                           (int)(row0 + k), (int)bs, (int)(col0 + k), (int)(col0 + k + bs), (int)tsize, (int)col0, (int)k,
+                           (int)trows, nrb, ncb, w.rank_count);
+        LU_TRY(hipGetLastError());
+        continue;
+      }
       if (k + nright > 0) {
         hipLaunchKernelGGL(lu_rowops<T>, dim3((unsigned)((k + nright + 63) / 64)), dim3(64), 0, s, base + col0 * ld, (int)k,
                            base + (col0 + k + bs) * ld, (int)nright, ld, transp, (int)(row0 + k), (int)(row0 + k + bs),
@@ -1895,6 +2061,13 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   static_assert(8 + kSets <= 32 && kSets * 8 <= 128, "the inverse flags and maxima must fit the 256-byte header");
   w.inverse_limit = kInverseGrowthLimit;
   if (const char* e = getenv("EIGAMD_LU_INVERSE_LIMIT")) w.inverse_limit = atof(e);  // 0: always substitute (tests)
+  {
+    static const bool fuse = [] { const char* e = getenv("EIGAMD_LU_FUSED_ROWOPS"); return !(e && atoi(e) == 0); }();
+    w.rank_count = fuse ? reinterpret_cast<int*>(p) + 52 : nullptr;   // bytes [208, 240) of the header, cleared below
+    w.rank_fused_max = 4608;
+    if (const char* e = getenv("EIGAMD_LU_FUSED_ROWOPS_MAX")) w.rank_fused_max = atoll(e);
+  }
+  static_assert(128 + kSets * 8 <= 208 && (kPlanSpan + kRankCols - 1) / kRankCols <= 8, "the counters of lu_rowops_rank_update must fit the header");
   w.partials = reinterpret_cast<Candidate<T>*>(p + off_partials);
   w.slots = reinterpret_cast<BaseSlot<T>*>(p + off_slots);
   LU_TRY(hipMemsetAsync(p, 0, 256, s));  // error flag of the fused base case, inverse flags and maxima
