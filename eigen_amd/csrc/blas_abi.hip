@@ -448,8 +448,17 @@ int gemm_host_small(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k
     pack(pin + off_b, dldb, b, ldb, b_rows, b_cols);
   }
   if (!beta_is_zero) pack(pin + off_c, dldc, c, ldc, m, n);
-  char* dev = st.dev;
-  if (up_bytes > 0) HIP_TRY(hipMemcpyAsync(dev, pin, up_bytes, hipMemcpyHostToDevice, st.stream));
+  // The smallest products skip both copies: the kernel reads its operands from the pinned chunk over the bus and
+  // writes C back into it (pinned host memory is addressable from the device); up to about a megabyte of operands
+  // two DMA transfers cost more than that (dgemm_ 64^3 43 -> 31 us, 128^3 58 -> 45, 192^3 93 -> 75; even at 256^3,
+  // slower from 320^3).  EIGAMD_HOST_ZERO_COPY_BYTES moves the limit (0: always copy).
+  static const size_t zero_copy_limit = [] {
+    const char* e = getenv("EIGAMD_HOST_ZERO_COPY_BYTES");
+    return e ? (size_t)atoll(e) : (size_t)1 << 20;
+  }();
+  const bool zero_copy = off_c + c_bytes <= zero_copy_limit;
+  char* dev = zero_copy ? pin : st.dev;
+  if (!zero_copy && up_bytes > 0) HIP_TRY(hipMemcpyAsync(dev, pin, up_bytes, hipMemcpyHostToDevice, st.stream));
   GemmCall call;
   call.kind = dtype; call.opa = opa; call.opb = opb;
   call.m = m; call.n = n; call.k = k;
@@ -460,8 +469,8 @@ int gemm_host_small(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k
   call.C = dev + off_c; call.ldc = dldc;
   call.serial_edges = true;  // (a product this small is one launch anyway; no helper streams)
   HIP_TRY(launch(call, st.stream));
-  char* back = st.down;
-  HIP_TRY(hipMemcpyAsync(back, dev + off_c, c_bytes, hipMemcpyDeviceToHost, st.stream));
+  char* back = zero_copy ? pin + off_c : st.down;
+  if (!zero_copy) HIP_TRY(hipMemcpyAsync(back, dev + off_c, c_bytes, hipMemcpyDeviceToHost, st.stream));
   HIP_TRY(hipStreamSynchronize(st.stream));
   // only the m x n window goes back: rows m..ldc-1 of C keep the caller's bytes
   char* cp = static_cast<char*>(c);
