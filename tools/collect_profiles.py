@@ -26,6 +26,27 @@ with open(os.path.join(R, "profiles", f"{tag}_kernel_trace_stats_bench.txt"), "w
         f.write(f"\nbench.py's own HIP-event average of the timed dgemm 16384^3 launches in the same run: {b['roofline']['avg_launch_ms']} ms "
                 f"(trace: {sum(head) / len(head):.3f} ms over the {len(head)} launches of that product, warm-up included; the other "
                 f"{len(durs) - len(head)} launches of the same grid are the SYRK and TRMM legs); value {b['value']} TFLOP/s\n")
+# per-variant table from the trace: kernel instantiation <kind, A k-contiguous, B k-contiguous> = operand forms
+# (A k-contiguous: 'T' or 'C' on A; B k-contiguous: 'N' on B; conjugation is a run-time flag of the same kernel),
+# full launches of the configured products only (within 10 % of the longest launch of that instantiation and grid)
+with open(os.path.join(R, "profiles", f"{tag}_kernel_trace_stats_bench.txt"), "a") as f:
+    f.write("\nper variant, from the trace (configured sizes; TFLOP/s = flops / average launch duration):\n")
+    f.write(" product            forms (A, B)      launches     avg_ms   TFLOP/s\n")
+    spec = [(1, "dgemm 16384^3", (16384 // 256) * (16384 // 128), 2.0 * 16384 ** 3),
+            (0, "sgemm 16384^3", (16384 // 256) * (16384 // 256), 2.0 * 16384 ** 3),
+            (3, "zgemm 8192^3", (8192 // 128) * (8192 // 128), 8.0 * 8192 ** 3),
+            (2, "cgemm 8192^3", (8192 // 128) * (8192 // 256), 8.0 * 8192 ** 3)]
+    for kind, label, wg, flops in spec:
+        for ak in ("false", "true"):
+            for bk in ("true", "false"):
+                name = f"%gemm_kernel<{kind}, {ak}, {bk}, false>%"
+                d = [x for (x,) in cur.execute("select (end-start)/1e6 from kernels where name like ? and grid_x/workgroup_x = ?", (name, wg))]
+                full = [x for x in d if x > 0.9 * max(d)] if d else []
+                if not full:
+                    continue
+                forms = ("T|C" if ak == "true" else "N") + ", " + ("N" if bk == "true" else "T|C")
+                avg = sum(full) / len(full)
+                f.write(f" {label:18s} {forms:16s} {len(full):9d} {avg:10.3f} {flops / avg / 1e9:9.2f}\n")
 json.dump(b, open(os.path.join(R, "profiles", f"{tag}_bench_n1.json"), "w"), indent=1)
 pmc = open(os.path.join(src, "pmc_gemm16384.txt")).read()
 open(os.path.join(R, "profiles", f"{tag}_pmc_gemm16384.txt"), "w").write(pmc)
