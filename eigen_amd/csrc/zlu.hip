@@ -152,6 +152,99 @@ __global__ void zlu_update(Z<R>* __restrict__ P, int64_t ld, int rows, int jbw, 
   }
 }
 
+// One pivot column in ONE launch (zlu_pivot and zlu_update together; EIGAMD_ZLU_ONE_LAUNCH=0 keeps the two).  Every
+// workgroup picks the pivot from the candidates of the launch before (all pick the same), reads panel rows jj and p
+// as they are, and eliminates its own rows with u = row p; the thread that owns row p works on what row jj held
+// instead of its own row and stores nothing.  Rows jj and p themselves are written once nobody reads them any more:
+// a workgroup counts itself in when its copies of them are in LDS, and the workgroup that completes the count stores
+// row jj <- old row p and row p <- eliminated old row jj at its end, and puts the counter back.  Nobody waits.  The
+// candidates of the next column go to the other of two buffers.  Same operations per element as the two launches.
+template <typename R>
+__global__ void __launch_bounds__(kRows) zlu_step(Z<R>* __restrict__ P, int64_t ld, int rows, int jbw, int jj,
+                                                  const Cand<R>* __restrict__ cand_in, int nin, Cand<R>* __restrict__ cand_out,
+                                                  int* __restrict__ transp, int row_offset, int col_global,
+                                                  int* __restrict__ first_zero, int* __restrict__ nswaps, int* __restrict__ counter) {
+  __shared__ Z<R> s_top[kBase], s_piv[kBase];  // rows jj and p of the panel before this column's exchange (s_piv = u)
+  __shared__ R s_best;
+  __shared__ int s_row, s_last;
+  const int t = threadIdx.x;
+  if (t < 64) {
+    R val = (R)-1;
+    int row = kNoRow;
+    for (int i = t; i < nin; i += 64) {
+      const Cand<R> c = cand_in[i];
+      if (better(c.val, c.row, val, row)) { val = c.val; row = c.row; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const R ov = __shfl_down(val, off, 64);
+      const int orow = __shfl_down(row, off, 64);
+      if (better(ov, orow, val, row)) { val = ov; row = orow; }
+    }
+    if (t == 0) {
+      if (row == kNoRow) {  // nothing comparable in the column (NaNs): no exchange, pivot = the diagonal entry
+        row = jj;
+        val = (R)1;
+      }
+      s_row = row;
+      s_best = val;
+    }
+  }
+  __syncthreads();
+  const int p = s_row;
+  const bool zero = !(s_best != (R)0);
+  const bool swap = !zero && p != jj;
+  if (t < jbw) {
+    const Z<R> top = P[jj + (int64_t)t * ld];
+    s_top[t] = top;
+    s_piv[t] = swap ? P[p + (int64_t)t * ld] : top;
+  }
+  __syncthreads();
+  if (t == 0) {  // this workgroup's copies of the two rows are in LDS
+    const int arrived = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = arrived == (int)gridDim.x - 1;
+    if (last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = last;
+    if (blockIdx.x == 0) {
+      transp[0] = row_offset + p;
+      if (zero) atomicCAS(first_zero, -1, col_global);  // the FIRST zero pivot (PartialPivLU.h:391-396)
+      else if (swap) atomicAdd(nswaps, 1);
+    }
+  }
+  const Z<R> pivot = s_piv[jj];
+  const int r = jj + 1 + blockIdx.x * kRows + t;
+  R cand = (R)-1;
+  if (r < rows) {
+    const bool is_p = swap && r == p;  // this row receives what row jj held; the last workgroup stores it
+    Z<R> l = is_p ? s_top[jj] : P[r + (int64_t)jj * ld];
+    if (!zero) {
+      l = l / pivot;  // the reference divides (lu.col(k).tail /= pivot, :389)
+      if (!is_p) P[r + (int64_t)jj * ld] = l;
+    }
+    for (int c = jj + 1; c < jbw; ++c) {
+      Z<R>* dst = P + r + (int64_t)c * ld;
+      const Z<R> x = (is_p ? s_top[c] : *dst) - l * s_piv[c];
+      if (!is_p) *dst = x;
+      if (c == jj + 1) cand = modulus(x);
+    }
+  }
+  if (jj + 1 < jbw) {
+    const Cand<R> c = block_best<R>(cand, r < rows ? r : kNoRow);
+    if (t == 0) cand_out[blockIdx.x] = c;
+  } else {
+    __syncthreads();
+  }
+  if (s_last && swap && t < jbw) {
+    P[jj + (int64_t)t * ld] = s_piv[t];
+    Z<R> v = s_top[t];
+    if (t >= jj) {
+      const Z<R> l = s_top[jj] / pivot;
+      v = t == jj ? l : s_top[t] - l * s_piv[t];
+    }
+    P[p + (int64_t)t * ld] = v;
+  }
+}
+
 // transpositions [k0, k1) on nleft + nright columns, and on the right-hand ones the forward substitution
 // with the unit lower jb x jb triangle L at rows [k0, k0 + jb); one thread per column
 template <typename R>
@@ -272,6 +365,8 @@ template <typename R> hipError_t zgemm_minus(int64_t m, int64_t n, int64_t k, co
 }
 
 template <typename R> struct ZWork {
+  Cand<R>* partials2;   // the second candidate buffer of zlu_step
+  int* count;           // its counter (zero between launches), or null: two launches per pivot column
   Cand<R>* partials;
   PivotRow<R>* side;
   int* first_zero;
@@ -284,6 +379,17 @@ hipError_t zunblocked(Z<R>* P, int64_t ld, int64_t rows, int jbw, int* transp, i
   const int size = (int)std::min<int64_t>(rows, jbw);
   int nparts = (int)((rows + kRows - 1) / kRows);
   hipLaunchKernelGGL(zlu_colmax<R>, dim3(nparts), dim3(kRows), 0, s, P, ld, (int)rows, w.partials);
+  if (w.count) {
+    Cand<R>* buf[2] = {w.partials, w.partials2};
+    for (int jj = 0; jj < size; ++jj) {
+      const int64_t below = rows - jj - 1;
+      const int nout = (int)std::max<int64_t>(1, (below + kRows - 1) / kRows);
+      hipLaunchKernelGGL(zlu_step<R>, dim3(nout), dim3(kRows), 0, s, P, ld, (int)rows, jbw, jj, buf[jj & 1], nparts, buf[(jj + 1) & 1],
+                         transp + jj, row_offset, col_offset + jj, w.first_zero, w.nswaps, w.count);
+      nparts = nout;
+    }
+    return hipGetLastError();
+  }
   for (int jj = 0; jj < size; ++jj) {
     hipLaunchKernelGGL(zlu_pivot<R>, dim3(1), dim3(64), 0, s, P, ld, jbw, jj, w.partials, nparts, transp + jj, row_offset,
                        col_offset + jj, w.side, w.first_zero, w.nswaps);
@@ -380,7 +486,8 @@ hipError_t zgetrf_t(int64_t m, int64_t n, Z<R>* A, int64_t ld, int* d_transp, in
   std::lock_guard<std::mutex> lock(sc.mu);
   const size_t nparts = (size_t)((m + kRows - 1) / kRows) + 1;
   const size_t off_side = 64, off_partials = off_side + (sizeof(PivotRow<R>) + 63) / 64 * 64;
-  const size_t need = off_partials + nparts * sizeof(Cand<R>);
+  const size_t partial_bytes = (nparts * sizeof(Cand<R>) + 63) / 64 * 64;
+  const size_t need = off_partials + 2 * partial_bytes;
   if (need > sc.cap) {
     if (sc.buf) ZLU_TRY(hipFree(sc.buf));
     sc.buf = nullptr; sc.cap = 0;
@@ -393,6 +500,10 @@ hipError_t zgetrf_t(int64_t m, int64_t n, Z<R>* A, int64_t ld, int* d_transp, in
   w.nswaps = w.first_zero + 1;
   w.side = reinterpret_cast<PivotRow<R>*>(p + off_side);
   w.partials = reinterpret_cast<Cand<R>*>(p + off_partials);
+  w.partials2 = reinterpret_cast<Cand<R>*>(p + off_partials + partial_bytes);
+  static const bool one_launch = [] { const char* e = getenv("EIGAMD_ZLU_ONE_LAUNCH"); return !(e && atoi(e) == 0); }();
+  w.count = one_launch ? reinterpret_cast<int*>(p) + 2 : nullptr;
+  ZLU_TRY(hipMemsetAsync(p, 0, 64, s));
   ZLU_TRY(hipMemsetAsync(w.first_zero, 0xFF, sizeof(int), s));  // -1
   ZLU_TRY(hipMemsetAsync(w.nswaps, 0, sizeof(int), s));
   const int nt = (int)std::min(m, n);
