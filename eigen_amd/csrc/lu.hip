@@ -2193,12 +2193,12 @@ __global__ void __launch_bounds__(256) lu_apply_plan_dir(T* __restrict__ A, int6
 // reverse order, kPlanSpan of them per pair of launches.
 template <typename T>
 hipError_t permute_rows(T* B, int64_t ldb, int64_t ncols, const int* transp, int64_t n, bool reverse, SwapPlan* plan,
-                        hipStream_t s) {
+                        hipStream_t s, int64_t first = 0) {
   constexpr int kCols = sizeof(T) > 8 ? 4 : 8;
-  const int64_t chunks = (n + kPlanSpan - 1) / kPlanSpan;
+  const int64_t chunks = (n - first + kPlanSpan - 1) / kPlanSpan;
   for (int64_t q = 0; q < chunks; ++q) {
     const int64_t c = reverse ? chunks - 1 - q : q;
-    const int k0 = (int)(c * kPlanSpan), k1 = (int)std::min<int64_t>(n, (c + 1) * kPlanSpan);
+    const int k0 = (int)(first + c * kPlanSpan), k1 = (int)std::min<int64_t>(n, first + (c + 1) * kPlanSpan);
     LU_TRY(make_plan(transp, k0, k1, plan, s));
     hipLaunchKernelGGL((lu_apply_plan_dir<T, kCols>), dim3((unsigned)((ncols + kCols - 1) / kCols)), dim3(256), 0, s, B, ldb,
                        ncols, plan, reverse ? 1 : 0);
@@ -2208,6 +2208,24 @@ hipError_t permute_rows(T* B, int64_t ldb, int64_t ncols, const int* transp, int
 }
 
 }  // namespace
+
+// laswp_device for the complex kinds: the transpositions [k0, k1) in order, kPlanSpan at a time as one permutation each.
+hipError_t laswp_device_complex(int kind, void* A, int64_t ld, int64_t ncols, const int* d_transp, int k0, int k1, hipStream_t s) {
+  if (kind != C32 && kind != C64) return hipErrorInvalidValue;
+  if (ncols <= 0 || k1 <= k0) return hipSuccess;
+  LuScratch& sc = scratch();
+  std::lock_guard<std::mutex> lock(sc.mu);
+  if (!sc.pub_plan) {
+    LU_TRY(hipMalloc(&sc.pub_plan, sizeof(SwapPlan)));
+    LU_TRY(hipEventCreateWithFlags(&sc.pub_plan_done, hipEventDisableTiming));
+  } else {
+    LU_TRY(hipStreamWaitEvent(s, sc.pub_plan_done, 0));
+  }
+  SwapPlan* plan = static_cast<SwapPlan*>(sc.pub_plan);
+  LU_TRY(kind == C32 ? permute_rows<Pair32>(static_cast<Pair32*>(A), ld, ncols, d_transp, k1, false, plan, s, k0)
+                     : permute_rows<Pair64>(static_cast<Pair64*>(A), ld, ncols, d_transp, k1, false, plan, s, k0));
+  return hipEventRecord(sc.pub_plan_done, s);
+}
 
 hipError_t getrs_device(int kind, int op, int64_t n, int64_t nrhs, const void* LU, int64_t ldlu, const int* d_transp, void* B,
                         int64_t ldb, hipStream_t s) {

@@ -33,6 +33,10 @@ hipError_t getrf_device_complex(int kind, int64_t m, int64_t n, void* A, int64_t
 hipError_t laswp_device(int kind, void* A, int64_t ld, int64_t ncols, const int* d_transp, int k0, int k1,
                         hipStream_t s);
 
+// The same for the complex kinds (C32, C64).
+hipError_t laswp_device_complex(int kind, void* A, int64_t ld, int64_t ncols, const int* d_transp, int k0, int k1,
+                                hipStream_t s);
+
 // B (bs x ncols) <- L^-1 B, L the unit lower triangle of a bs x bs block.
 hipError_t trsm_llnu_device(int kind, int64_t bs, int64_t ncols, const void* L, int64_t ldl, void* B, int64_t ldb,
                             hipStream_t s);

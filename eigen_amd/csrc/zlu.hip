@@ -405,6 +405,9 @@ hipError_t zunblocked(Z<R>* P, int64_t ld, int64_t rows, int jbw, int* transp, i
 template <typename R>
 hipError_t zlaswp(Z<R>* A, int64_t ld, int64_t ncols, const int* transp, int k0, int k1, hipStream_t s) {
   if (ncols <= 0 || k1 <= k0) return hipSuccess;
+  // long runs: as permutations of 256 transpositions with independent loads (lu.hip) instead of a chain of dependent
+  // exchanges per column (256 of them: 0.25 ms whatever the number of columns)
+  if (k1 - k0 > 32) return laswp_device_complex(ZKind<R>::value, A, ld, ncols, transp, k0, k1, s);
   hipLaunchKernelGGL(zlu_laswp<R>, dim3((unsigned)((ncols + 127) / 128)), dim3(128), 0, s, A, ld, (int)ncols, transp, k0, k1);
   return hipGetLastError();
 }
