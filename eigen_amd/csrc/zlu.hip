@@ -17,6 +17,7 @@
 
 #include "gemm_launch.hpp"
 #include "lu.hpp"
+#include "trsm.hpp"
 
 namespace eigamd {
 
@@ -460,7 +461,12 @@ hipError_t zblocked(Z<R>* base, int64_t ld, int64_t row0, int64_t col0, int64_t 
     ZLU_TRY(zlaswp<R>(base + col0 * ld, ld, k, transp, (int)(row0 + k), (int)(row0 + k + bs), s));                 // A_0 (:479-483)
     if (trows && tsize > 0) {
       ZLU_TRY(zlaswp<R>(base + (col0 + k + bs) * ld, ld, tsize, transp, (int)(row0 + k), (int)(row0 + k + bs), s));  // A_2 (:488-489)
-      for (int64_t j = 0; j < bs; j += 32) {                                                                        // (:492)
+      static const bool lib_solve = [] { const char* e = getenv("EIGAMD_ZLU_TRSM"); return !(e && atoi(e) == 0); }();
+      if (lib_solve && bs >= 64) {  // the library's triangular solve (inverted 128-wide blocks, guarded; trsm.hip)       // (:492)
+        const double one[2] = {1.0, 0.0};
+        ZLU_TRY(trsm_device(ZKind<R>::value, true, false, OP_N, true, bs, tsize, one, A11, ld, A12, ld, s));
+      } else
+      for (int64_t j = 0; j < bs; j += 32) {
         const int jb = (int)std::min<int64_t>(32, bs - j);
         hipLaunchKernelGGL(zlu_trsm_small<R>, dim3((unsigned)((tsize + 63) / 64)), dim3(64), 0, s, A11 + j + j * ld, ld, A12 + j, ld, jb,
                            (int)tsize);
