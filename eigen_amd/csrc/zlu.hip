@@ -297,7 +297,23 @@ __global__ void __launch_bounds__(256) zlu_rank_update(const Z<R>* __restrict__ 
     const Z<R> z = {(R)0, (R)0};
     a[k] = k < jb ? A[r + (int64_t)k * ld] : z;
   }
-  for (int j = 0; j < nc; ++j) {
+  // groups of 8 columns: their loads are independent and in flight together (one at a time, the kernel waited for
+  // memory sixteen times per row)
+  constexpr int kGroup = 8;
+  int j = 0;
+  for (; j + kGroup <= nc; j += kGroup) {
+    Z<R> acc[kGroup];
+#pragma unroll
+    for (int u = 0; u < kGroup; ++u) acc[u] = C[r + (int64_t)(c0 + j + u) * ld];
+#pragma unroll
+    for (int u = 0; u < kGroup; ++u) {
+#pragma unroll
+      for (int k = 0; k < kBase; ++k) acc[u] = acc[u] - a[k] * s_b[k][j + u];
+    }
+#pragma unroll
+    for (int u = 0; u < kGroup; ++u) C[r + (int64_t)(c0 + j + u) * ld] = acc[u];
+  }
+  for (; j < nc; ++j) {
     Z<R> acc = C[r + (int64_t)(c0 + j) * ld];
 #pragma unroll
     for (int k = 0; k < kBase; ++k) acc = acc - a[k] * s_b[k][j];
