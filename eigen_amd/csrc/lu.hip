@@ -1937,8 +1937,8 @@ void release_lu_streams() {
 // workgroups of the trailing GEMM.  Bit b of a CU mask is compute unit b / 8 of XCD b % 8, so
 // a run of bits takes the same number of CUs from every XCD.  The fused base case needs all
 // its workgroups resident (`per_cu` fit on a CU): a taller panel gets more CUs.
-hipError_t make_streams(LuStreams& st, int base_workgroups, int per_cu, int* total_cus) {
-  int want = 32;
+hipError_t make_streams(LuStreams& st, int base_workgroups, int per_cu, int* total_cus, int default_cus) {
+  int want = default_cus;
   if (const char* e = getenv("EIGAMD_LU_PANEL_CUS")) want = atoi(e);
   hipDeviceProp_t prop;
   int dev = 0;
@@ -2074,10 +2074,17 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   LU_TRY(hipMemsetAsync(w.first_zero, 0xFF, sizeof(int), s));  // -1
   LU_TRY(hipMemsetAsync(w.nswaps, 0, sizeof(int), s));
   int per_cu = 0, total_cus = 0;
+  // Up to 16384 columns the factorisation waits for the panel chain from start to end, and a panel of up to 64
+  // workgroups runs faster with a compute unit per workgroup (8192^2 50.6 -> 48.5 ms, 12288^2 84.7 -> 80.0, 16384^2
+  // 126.9 -> 124.9 with 64 instead of 32 compute units; 20480^2 183 -> 188: there the trailing products need them).
+  // (The streams are rebuilt when the split changes from one call to the next: a few hardware queues serve all the
+  // streams of a process, and a second set kept alive would share them with the first.)
+  const bool panel_bound = std::min(m, n) <= 16384;
+  LuStreams& streams = sc.streams;
   LU_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lu_base_fused<T>, kRowsPerBlock, 0));
   per_cu = std::max(per_cu, 1);
   if (max_block > 16) {
-    LU_TRY(make_streams(sc.streams, (int)(nparts - 1), per_cu, &total_cus));
+    LU_TRY(make_streams(streams, (int)(nparts - 1), per_cu, &total_cus, panel_bound ? 64 : 32));
   } else {
     hipDeviceProp_t prop;
     int dev = 0;
@@ -2085,7 +2092,7 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
     LU_TRY(hipGetDeviceProperties(&prop, dev));
     total_cus = prop.multiProcessorCount;
   }
-  const int panel_cus = (max_block > 16 && sc.streams.panel_cus > 0) ? sc.streams.panel_cus : total_cus;
+  const int panel_cus = (max_block > 16 && streams.panel_cus > 0) ? streams.panel_cus : total_cus;
   w.fused_capacity = std::min(kMaxFusedParts, per_cu * panel_cus);
   {
     const int nt = (int)std::min(m, n);
@@ -2093,7 +2100,7 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
     LU_TRY(hipGetLastError());
   }
   if (max_block > 16) {
-    LU_TRY(blocked_lookahead<T>(A, ld, m, n, d_transp, max_block, w, sc.streams, s));
+    LU_TRY(blocked_lookahead<T>(A, ld, m, n, d_transp, max_block, w, streams, s));
   } else {  // a panel: nothing to overlap with
     LU_TRY(blocked<T>(A, ld, 0, 0, m, n, d_transp, max_block, w, s));
   }
