@@ -333,7 +333,12 @@ Staging& staging() {
 int64_t round_up(int64_t v, int64_t q) { return (v + q - 1) / q * q; }
 
 // When a host-pointer product is dealt out over several devices (read at every call: cheap, and
-// tests change the variables between calls).
+// tests change the variables between calls).  The route is taken on request only -- EIGAMD_MULTI_GPU=1:
+// every visible device, or EIGAMD_MULTI_GPU_VIRTUAL=P (tests): P ranks on the current device -- because a
+// grid allocates memory on every device it spans, and a process that is one of several sharing the node
+// must not spread over its neighbours' devices: a launcher that gives every device its own process is
+// recognised by its environment (WORLD_SIZE, LOCAL_WORLD_SIZE, OMPI_COMM_WORLD_SIZE, PMI_SIZE, SLURM_NTASKS
+// above 1) and wins over the request.
 struct MultiGpuRule {
   int ranks = 1;
   bool virtual_grid = false;
@@ -346,9 +351,11 @@ MultiGpuRule multi_gpu_rule() {
     r.ranks = std::max(1, atoi(e));
     r.virtual_grid = true;
   } else {
-    const char* off = getenv("EIGAMD_MULTI_GPU");
-    const char* world = getenv("WORLD_SIZE");
-    if ((off && atoi(off) == 0) || (world && atoi(world) > 1)) return r;
+    const char* on = getenv("EIGAMD_MULTI_GPU");
+    if (!on || atoi(on) == 0) return r;
+    for (const char* name : {"WORLD_SIZE", "LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "SLURM_NTASKS"})
+      if (const char* v = getenv(name))
+        if (atoi(v) > 1) return r;
     int count = 1;
     if (hipGetDeviceCount(&count) != hipSuccess) count = 1;
     r.ranks = std::min(count, 8);
@@ -412,8 +419,15 @@ int small_context_acquire(SmallContext** out) {
 struct SmallContextLease {  // hands the context back when the call ends, whichever way
   SmallContext* c = nullptr;
   SmallPool* pool = nullptr;
+  bool at_rest = false;   // the call has waited for its stream: nothing queued on it still touches the context's buffers
   ~SmallContextLease() {
     if (!c) return;
+    // An early return (a failed copy or launch) may leave a copy or the kernel in flight on the pinned chunks and the
+    // device buffer; the next borrower would repack them underneath that work.
+    if (!at_rest) {
+      (void)hipStreamSynchronize(c->stream);
+      (void)hipGetLastError();
+    }
     std::lock_guard<std::mutex> lock(pool->mu);
     pool->idle.push_back(c);
   }
@@ -472,6 +486,7 @@ int gemm_host_small(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k
   char* back = zero_copy ? pin + off_c : st.down;
   if (!zero_copy) HIP_TRY(hipMemcpyAsync(back, dev + off_c, c_bytes, hipMemcpyDeviceToHost, st.stream));
   HIP_TRY(hipStreamSynchronize(st.stream));
+  lease.at_rest = true;
   // only the m x n window goes back: rows m..ldc-1 of C keep the caller's bytes
   char* cp = static_cast<char*>(c);
   for (int64_t j = 0; j < n; ++j) std::memcpy(cp + (size_t)j * ldc * es, back + (size_t)j * dldc * es, (size_t)m * es);
@@ -487,11 +502,9 @@ int gemm_host_impl(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k,
   int rc = ensure_device();
   if (rc != EIGAMD_OK) return rc;
 
-  // Several GPUs visible: a large product is dealt out over all of them (eigamd_pgemm_host), as
+  // On request (multi_gpu_rule) a large product is dealt out over all visible GPUs (eigamd_pgemm_host), as
   // the reference splits one over the cores without the caller noticing (parallelize_gemm,
-  // Eigen/src/Core/products/Parallelizer.h:101-176).  Not when this process is one rank of a
-  // launcher that gives every GPU its own process (WORLD_SIZE > 1), and not with EIGAMD_MULTI_GPU=0.
-  // EIGAMD_MULTI_GPU_VIRTUAL=P (tests): P ranks on the current device.
+  // Eigen/src/Core/products/Parallelizer.h:101-176).
   if (c_inc == 1 && k > 0) {
     const MultiGpuRule rule = multi_gpu_rule();
     if (rule.ranks > 1 && (double)m * (double)n * (double)k >= rule.min_work && m >= 2 * rule.nb && n >= 2 * rule.nb) {
@@ -608,20 +621,29 @@ namespace eigamd {
 int abi_fail(int code, const std::string& what) { return fail(code, what); }  // for the other translation units of the ABI
 
 // rows x cols elements between a caller's (pageable) matrix and memory of the current device, through
-// this device's pinned chunks and copy threads; returns when the data has arrived.  (Asynchronous 2-D
+// this device's pinned chunks and copy threads; returns when the data has arrived (an upload with wait = false:
+// once it is queued; staged_upload_wait then waits for all of them).  (Asynchronous 2-D
 // copies straight from pageable memory, issued on several streams for neighbouring blocks of one host
 // matrix, made the runtime abort now and then; the staged form is also five times faster.)
-int staged_copy(bool to_device, void* dev, int64_t dld, void* host, int64_t ld, int64_t rows, int64_t cols, int es) {
+int staged_copy(bool to_device, void* dev, int64_t dld, void* host, int64_t ld, int64_t rows, int64_t cols, int es, bool wait) {
   Staging& st = staging();
   std::lock_guard<std::mutex> lock(st.mu);
   int rc = st.init();
   if (rc != EIGAMD_OK) return rc;
   if (to_device) {
     if ((rc = st.upload(dev, dld, host, ld, rows, cols, es)) != EIGAMD_OK) return rc;
-    HIP_TRY(hipStreamSynchronize(st.h2d));
+    if (wait) HIP_TRY(hipStreamSynchronize(st.h2d));
     return EIGAMD_OK;
   }
   return st.download(host, ld, dev, dld, rows, cols, es);
+}
+int staged_upload_wait() {
+  Staging& st = staging();
+  std::lock_guard<std::mutex> lock(st.mu);
+  int rc = st.init();
+  if (rc != EIGAMD_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(st.h2d));
+  return EIGAMD_OK;
 }
 namespace {
 struct EdgeStreams {

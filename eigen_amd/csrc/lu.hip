@@ -724,6 +724,7 @@ __global__ void lu_laswp(T* __restrict__ A, int64_t ld, int ncols, const int* __
 #define EIGAMD_LU_RANK_COLS 32
 #endif
 constexpr int kRankCols = EIGAMD_LU_RANK_COLS;
+constexpr int kRankCounters = 8;   // arrival counters of lu_rowops_rank_update: bytes [208, 240) of the scratch header
 template <typename T>
 __global__ void __launch_bounds__(256) lu_rank_update(const T* __restrict__ A, const T* __restrict__ B, T* __restrict__ C,
                                                       int64_t ld, int rows, int cols, int jb) {
@@ -1622,8 +1623,13 @@ hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows
       // Narrow blocks (inside a panel): the transpositions on both sides (A_0 :479-483, A_2
       // :488-489) and the triangular solve (:492) in one launch, then the rank-bs update (:494).
       const int64_t nright = trows ? tsize : 0;
-      if (w.rank_count && trows > 0 && trows <= w.rank_fused_max && tsize > 0) {   // row operations and rank update in one launch
-        const int nrb = (int)((trows + 255) / 256), ncb = (int)((tsize + kRankCols - 1) / kRankCols);
+      // Row operations and rank update in one launch: one arrival counter per 32-column block, kRankCounters of
+      // them in the header.  A panel of the look-ahead has at most kPlanSpan columns right of a block; a caller
+      // that hands a wide matrix to blocked() with blocks of 16 (max_block_size <= 16) may have more, and takes
+      // the two launches.
+      const int ncb = (int)((tsize + kRankCols - 1) / kRankCols);
+      if (w.rank_count && trows > 0 && trows <= w.rank_fused_max && tsize > 0 && ncb <= kRankCounters) {
+        const int nrb = (int)((trows + 255) / 256);
         const int nleft_wg = (int)((k + 255) / 256);
         hipLaunchKernelGGL(lu_rowops_rank_update<T>, dim3((unsigned)(nrb * ncb + nleft_wg)), dim3(256), 0, s, base, ld, transp,
                            (int)(row0 + k), (int)bs, (int)(col0 + k), (int)(col0 + k + bs), (int)tsize, (int)col0, (int)k,
@@ -1897,6 +1903,11 @@ struct LuScratch {
   int kind = -1;            // element type the exchange area was last used with
   void* pub_plan = nullptr; // plan scratch of laswp_device
   hipEvent_t pub_plan_done = nullptr;
+  // Behind the last factorisation that used `buf`.  A call that does not wait (d_info) returns with its kernels
+  // still queued, and the header, plans, inverses and exchange area belong to them until they have run: the next
+  // factorisation on this device, from whatever stream or thread, waits for this event first.
+  hipEvent_t buf_done = nullptr;
+  bool buf_busy = false;    // buf_done has been recorded by a call that did not wait
   LuStreams streams;
 };
 LuScratch& scratch() {
@@ -2014,6 +2025,12 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   const size_t off_linv = off_plan + kSets * round64(sizeof(SwapPlan));
   const size_t off_partials = off_linv + kSets * round64((size_t)kPlanSpan * kPlanSpan * sizeof(T));
   const size_t need = off_partials + round64(nparts * sizeof(Candidate<T>));
+  if (!sc.buf_done) LU_TRY(hipEventCreateWithFlags(&sc.buf_done, hipEventDisableTiming));
+  if (sc.buf_busy) {
+    if (need > sc.cap) LU_TRY(hipEventSynchronize(sc.buf_done));  // (the buffer is about to be freed)
+    else LU_TRY(hipStreamWaitEvent(s, sc.buf_done, 0));
+    sc.buf_busy = false;
+  }
   if (need > sc.cap) {
     if (sc.buf) LU_TRY(hipFree(sc.buf));
     sc.buf = nullptr;
@@ -2067,7 +2084,8 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
     w.rank_fused_max = 4608;
     if (const char* e = getenv("EIGAMD_LU_FUSED_ROWOPS_MAX")) w.rank_fused_max = atoll(e);
   }
-  static_assert(128 + kSets * 8 <= 208 && (kPlanSpan + kRankCols - 1) / kRankCols <= 8, "the counters of lu_rowops_rank_update must fit the header");
+  static_assert(128 + kSets * 8 <= 208 && 208 + kRankCounters * 4 <= 256 && (kPlanSpan + kRankCols - 1) / kRankCols <= kRankCounters,
+                "the counters of lu_rowops_rank_update must fit the header and cover a panel of the look-ahead");
   w.partials = reinterpret_cast<Candidate<T>*>(p + off_partials);
   w.slots = reinterpret_cast<BaseSlot<T>*>(p + off_slots);
   LU_TRY(hipMemsetAsync(p, 0, 256, s));  // error flag of the fused base case, inverse flags and maxima
@@ -2106,7 +2124,10 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   }
   if (d_info) {  // the caller reads the counters from device memory, behind `s`: nothing to wait for
     hipLaunchKernelGGL(lu_export_info, dim3(1), dim3(1), 0, s, w.first_zero, d_info);
-    return hipGetLastError();
+    LU_TRY(hipGetLastError());
+    LU_TRY(hipEventRecord(sc.buf_done, s));
+    sc.buf_busy = true;
+    return hipSuccess;
   }
   int out[5] = {-1, 0, 0, 0, 0};
   LU_TRY(hipMemcpyAsync(out, w.first_zero, sizeof out, hipMemcpyDeviceToHost, s));

@@ -28,9 +28,12 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/eigen_amd_blas.h"
@@ -38,7 +41,8 @@
 
 namespace eigamd {
 int abi_fail(int code, const std::string& what);  // blas_abi.hip: sets eigamd_last_error()
-int staged_copy(bool to_device, void* dev, int64_t dld, void* host, int64_t ld, int64_t rows, int64_t cols, int es);
+int staged_copy(bool to_device, void* dev, int64_t dld, void* host, int64_t ld, int64_t rows, int64_t cols, int es, bool wait = true);
+int staged_upload_wait();   // until every upload queued so far on the current device's staging handle has landed
 }
 using namespace eigamd;
 
@@ -344,32 +348,69 @@ int issue_products(eigamd_pgemm& g, int64_t p, const double alpha[2], const doub
 
 // Host <-> local parts, block by block through the owning device's pinned staging (block (bi, bj) of
 // the stored matrix lives on the rank whose grid coordinates are the block indices modulo the grid
-// extents).  Synchronous; the local parts must be at rest (eigamd_pgemm_sync) before a gather.
-int move_blocks(eigamd_pgemm& g, int which, char* host, int64_t ld, bool to_device) {
+// extents).  `only_dev` >= 0 restricts the walk to the blocks of ranks on that device, `kpanel` >= 0 to the
+// blocks of an operand (A or B) that belong to that panel of the reduction.  Downloads are synchronous (the
+// local parts must be at rest); uploads return once queued unless `wait`.
+int move_blocks(eigamd_pgemm& g, int which, char* host, int64_t ld, bool to_device, int only_dev = -1, int64_t kpanel = -1,
+                bool wait = true) {
   // stored extents and which grid dimension deals out the stored rows / columns
   int64_t rows, cols;
   bool rows_over_grid_rows;  // stored rows dealt over grid rows (else over grid columns)
-  if (which == 0) { rows = g.a_rows_is_m ? g.m : g.k; cols = g.a_rows_is_m ? g.k : g.m; rows_over_grid_rows = g.a_rows_is_m; }
-  else if (which == 1) { rows = g.b_rows_is_k ? g.k : g.n; cols = g.b_rows_is_k ? g.n : g.k; rows_over_grid_rows = g.b_rows_is_k; }
+  bool k_is_rows = false;    // the reduction index runs along the stored rows (else along the stored columns)
+  if (which == 0) { rows = g.a_rows_is_m ? g.m : g.k; cols = g.a_rows_is_m ? g.k : g.m; rows_over_grid_rows = g.a_rows_is_m; k_is_rows = !g.a_rows_is_m; }
+  else if (which == 1) { rows = g.b_rows_is_k ? g.k : g.n; cols = g.b_rows_is_k ? g.n : g.k; rows_over_grid_rows = g.b_rows_is_k; k_is_rows = g.b_rows_is_k; }
   else { rows = g.m; cols = g.n; rows_over_grid_rows = true; }
   if (ld < std::max<int64_t>(rows, 1)) return abi_fail(EIGAMD_ERR_ARG, "leading dimension smaller than the stored rows");
   const int np_r = rows_over_grid_rows ? g.nprow : g.npcol, np_c = rows_over_grid_rows ? g.npcol : g.nprow;
   for (int64_t bj = 0; bj * g.nb < cols; ++bj) {
+    if (which < 2 && kpanel >= 0 && !k_is_rows && bj != kpanel) continue;
     for (int64_t bi = 0; bi * g.nb < rows; ++bi) {
+      if (which < 2 && kpanel >= 0 && k_is_rows && bi != kpanel) continue;
       const int qr = (int)(bi % np_r), qc = (int)(bj % np_c);
       Rank& r = rows_over_grid_rows ? g.at(qr, qc) : g.at(qc, qr);
+      if (only_dev >= 0 && r.dev != only_dev) continue;
       Local& l = which == 0 ? r.a : (which == 1 ? r.b : r.c);
       const int64_t nr = std::min(g.nb, rows - bi * g.nb), nc = std::min(g.nb, cols - bj * g.nb);
       char* dev = static_cast<char*>(l.ptr) + (size_t)((bi / np_r) * g.nb + (bj / np_c) * g.nb * l.ld) * g.es;
       char* hst = host + (size_t)(bi * g.nb + bj * g.nb * ld) * g.es;
       DeviceGuard dg(r.dev);
-      PG_TRY(staged_copy(to_device, dev, l.ld, hst, ld, nr, nc, g.es));
+      PG_TRY(staged_copy(to_device, dev, l.ld, hst, ld, nr, nc, g.es, wait));
     }
   }
   return EIGAMD_OK;
 }
 
 bool stored_rows_first(int op) { return op == OP_N || op == OP_CONJ; }
+
+// The copy streams start behind whatever filled the local parts, on every rank (a piece is read on its
+// owner's device by every receiver).
+int run_prologue(eigamd_pgemm& g) {
+  for (Rank& r : g.ranks) {
+    DeviceGuard dg(r.dev);
+    PG_HIP(hipEventRecord(r.done, r.compute));
+    PG_HIP(hipStreamWaitEvent(r.comm, r.done, 0));
+  }
+  if (g.ranks.size() > 1)
+    for (Rank& r : g.ranks)
+      for (Rank& o : g.ranks)
+        if (&o != &r) {
+          DeviceGuard dg(r.dev);
+          PG_HIP(hipStreamWaitEvent(r.comm, o.done, 0));
+        }
+  return EIGAMD_OK;
+}
+
+void read_scalars(int dtype, const void* alpha, const void* beta, double al[2], double be[2]) {
+  al[0] = al[1] = be[0] = be[1] = 0.0;
+  switch (dtype) {
+    case F32: al[0] = *static_cast<const float*>(alpha); be[0] = *static_cast<const float*>(beta); break;
+    case F64: al[0] = *static_cast<const double*>(alpha); be[0] = *static_cast<const double*>(beta); break;
+    case C32: al[0] = static_cast<const float*>(alpha)[0]; al[1] = static_cast<const float*>(alpha)[1];
+              be[0] = static_cast<const float*>(beta)[0]; be[1] = static_cast<const float*>(beta)[1]; break;
+    default:  al[0] = static_cast<const double*>(alpha)[0]; al[1] = static_cast<const double*>(alpha)[1];
+              be[0] = static_cast<const double*>(beta)[0]; be[1] = static_cast<const double*>(beta)[1]; break;
+  }
+}
 
 }  // namespace
 
@@ -493,15 +534,8 @@ int eigamd_pgemm_local(eigamd_pgemm* g, int which, int rank, void** ptr, int64_t
 
 int eigamd_pgemm_run(eigamd_pgemm* g, const void* alpha, const void* beta) {
   if (!g || !alpha || !beta) return abi_fail(EIGAMD_ERR_ARG, "invalid pgemm_run arguments");
-  double al[2] = {0, 0}, be[2] = {0, 0};
-  switch (g->dtype) {
-    case F32: al[0] = *static_cast<const float*>(alpha); be[0] = *static_cast<const float*>(beta); break;
-    case F64: al[0] = *static_cast<const double*>(alpha); be[0] = *static_cast<const double*>(beta); break;
-    case C32: al[0] = static_cast<const float*>(alpha)[0]; al[1] = static_cast<const float*>(alpha)[1];
-              be[0] = static_cast<const float*>(beta)[0]; be[1] = static_cast<const float*>(beta)[1]; break;
-    default:  al[0] = static_cast<const double*>(alpha)[0]; al[1] = static_cast<const double*>(alpha)[1];
-              be[0] = static_cast<const double*>(beta)[0]; be[1] = static_cast<const double*>(beta)[1]; break;
-  }
+  double al[2], be[2];
+  read_scalars(g->dtype, alpha, beta, al, be);
   const int64_t npanels = (g->k + g->nb - 1) / g->nb;
   const double one[2] = {1.0, 0.0};
   if (npanels == 0) {  // k == 0: C <- beta C (blas/level3_impl.h:62-69)
@@ -517,19 +551,7 @@ int eigamd_pgemm_run(eigamd_pgemm* g, const void* alpha, const void* beta) {
     }
     return EIGAMD_OK;
   }
-  // the copy streams start behind whatever filled the local parts
-  for (Rank& r : g->ranks) {
-    DeviceGuard dg(r.dev);
-    PG_HIP(hipEventRecord(r.done, r.compute));
-    PG_HIP(hipStreamWaitEvent(r.comm, r.done, 0));
-  }
-  if (g->ranks.size() > 1)  // a piece is read on its owner's device by every receiver
-    for (Rank& r : g->ranks)
-      for (Rank& o : g->ranks)
-        if (&o != &r) {
-          DeviceGuard dg(r.dev);
-          PG_HIP(hipStreamWaitEvent(r.comm, o.done, 0));
-        }
+  PG_TRY(run_prologue(*g));
   PG_TRY(issue_panel(*g, 0));
   for (int64_t p = 0; p < npanels; ++p) {
     if (p + 1 < npanels) PG_TRY(issue_panel(*g, p + 1));  // one panel ahead of the products
@@ -548,21 +570,107 @@ int eigamd_pgemm_sync(eigamd_pgemm* g) {
   return EIGAMD_OK;
 }
 
+// One call from host memory to host memory.  The route is bound by the host links, so everything that can
+// overlap does: every device of the grid has a host thread of its own that moves that device's blocks through
+// that device's pinned staging (one PCIe link each); the operands go up in the order the reduction consumes
+// them -- panel 0 of A and B, then C (not at all when beta == 0: the first product overwrites), then the other
+// panels -- and the calling thread issues the broadcast and the products of panel p as soon as every device has
+// reported panel p landed, so the products run underneath the upload of the later panels; when its last product
+// has been queued every device thread waits for it and brings its own blocks of C back.
 int eigamd_pgemm_host(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k, const void* alpha, const void* a,
                       int64_t lda, const void* b, int64_t ldb, const void* beta, void* c, int64_t ldc, int nprow, int npcol,
                       int64_t nb, const int* devices, int transport) {
   if (m == 0 || n == 0) return EIGAMD_OK;
+  if (!alpha || !beta || !c || (k > 0 && (!a || !b))) return abi_fail(EIGAMD_ERR_ARG, "invalid pgemm_host arguments");
   eigamd_pgemm* g = nullptr;
   PG_TRY(eigamd_pgemm_create(dtype, opa, opb, m, n, k, nprow, npcol, nb, devices, transport, &g));
+  double al[2], be[2];
+  read_scalars(dtype, alpha, beta, al, be);
+  const bool beta_is_zero = be[0] == 0.0 && be[1] == 0.0;
+  const int64_t npanels = (k + nb - 1) / nb;
   int rc = EIGAMD_OK;
-  if (k > 0) {
-    rc = eigamd_pgemm_scatter(g, 0, a, lda);
-    if (rc == EIGAMD_OK) rc = eigamd_pgemm_scatter(g, 1, b, ldb);
+  if (npanels == 0) {  // nothing to multiply: C <- beta C
+    if (!beta_is_zero) rc = eigamd_pgemm_scatter(g, 2, c, ldc);
+    if (rc == EIGAMD_OK) rc = eigamd_pgemm_run(g, alpha, beta);
+    if (rc == EIGAMD_OK) rc = eigamd_pgemm_sync(g);
+    if (rc == EIGAMD_OK) rc = eigamd_pgemm_gather(g, 2, c, ldc);
+    eigamd_pgemm_destroy(g);
+    return rc;
   }
-  if (rc == EIGAMD_OK) rc = eigamd_pgemm_scatter(g, 2, c, ldc);
-  if (rc == EIGAMD_OK) rc = eigamd_pgemm_run(g, alpha, beta);
-  if (rc == EIGAMD_OK) rc = eigamd_pgemm_sync(g);
-  if (rc == EIGAMD_OK) rc = eigamd_pgemm_gather(g, 2, c, ldc);
+  std::vector<int> devs;
+  for (const Rank& r : g->ranks)
+    if (std::find(devs.begin(), devs.end(), r.dev) == devs.end()) devs.push_back(r.dev);
+  struct Shared {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<int> landed;   // landed[p]: devices whose blocks of panel p (and, with p == 0, of C) are in device memory
+    bool issued = false;       // every product has been queued and Rank::done recorded behind the last one
+    int rc = EIGAMD_OK;        // first failure of any thread
+  } sh;
+  sh.landed.assign((size_t)npanels, 0);
+  char* ah = const_cast<char*>(static_cast<const char*>(a));
+  char* bh = const_cast<char*>(static_cast<const char*>(b));
+  char* ch = static_cast<char*>(c);
+  auto fail_with = [&](int code) {
+    std::lock_guard<std::mutex> l(sh.mu);
+    if (sh.rc == EIGAMD_OK) sh.rc = code;
+    sh.cv.notify_all();
+  };
+  auto device_thread = [&](int dev) {
+    if (hipSetDevice(dev) != hipSuccess) { fail_with(abi_fail(EIGAMD_ERR_DEVICE, "hipSetDevice failed in a copy thread")); return; }
+    for (int64_t p = 0; p < npanels; ++p) {
+      int e = move_blocks(*g, 0, ah, lda, true, dev, p, false);
+      if (e == EIGAMD_OK) e = move_blocks(*g, 1, bh, ldb, true, dev, p, false);
+      if (e == EIGAMD_OK && p == 0 && !beta_is_zero) e = move_blocks(*g, 2, ch, ldc, true, dev, -1, false);
+      if (e == EIGAMD_OK) e = staged_upload_wait();
+      if (e != EIGAMD_OK) { fail_with(e); return; }
+      {
+        std::lock_guard<std::mutex> l(sh.mu);
+        if (sh.rc != EIGAMD_OK) return;
+        ++sh.landed[(size_t)p];
+      }
+      sh.cv.notify_all();
+    }
+    {
+      std::unique_lock<std::mutex> l(sh.mu);
+      sh.cv.wait(l, [&] { return sh.issued || sh.rc != EIGAMD_OK; });
+      if (sh.rc != EIGAMD_OK) return;
+    }
+    for (Rank& r : g->ranks)
+      if (r.dev == dev && hipEventSynchronize(r.done) != hipSuccess) {
+        fail_with(abi_fail(EIGAMD_ERR_DEVICE, "waiting for a device's last product failed"));
+        return;
+      }
+    const int e = move_blocks(*g, 2, ch, ldc, false, dev);
+    if (e != EIGAMD_OK) fail_with(e);
+  };
+  std::vector<std::thread> threads;
+  for (int d : devs) threads.emplace_back(device_thread, d);
+  const double one[2] = {1.0, 0.0};
+  rc = run_prologue(*g);
+  for (int64_t p = 0; rc == EIGAMD_OK && p < npanels; ++p) {
+    {
+      std::unique_lock<std::mutex> l(sh.mu);
+      sh.cv.wait(l, [&] { return sh.landed[(size_t)p] == (int)devs.size() || sh.rc != EIGAMD_OK; });
+      if (sh.rc != EIGAMD_OK) break;
+    }
+    rc = issue_panel(*g, p);
+    if (rc == EIGAMD_OK) rc = issue_products(*g, p, al, p == 0 ? be : one);
+  }
+  if (rc == EIGAMD_OK)
+    for (Rank& r : g->ranks) {
+      DeviceGuard dg(r.dev);
+      if (hipEventRecord(r.done, r.compute) != hipSuccess) { rc = abi_fail(EIGAMD_ERR_DEVICE, "hipEventRecord failed"); break; }
+    }
+  if (rc != EIGAMD_OK) fail_with(rc);
+  {
+    std::lock_guard<std::mutex> l(sh.mu);
+    sh.issued = true;
+  }
+  sh.cv.notify_all();
+  for (std::thread& t : threads) t.join();
+  if (rc == EIGAMD_OK) rc = sh.rc;
+  (void)eigamd_pgemm_sync(g);
   eigamd_pgemm_destroy(g);
   return rc;
 }

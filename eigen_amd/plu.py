@@ -67,7 +67,9 @@ class DeviceOps:
         from .lu import getrf_dev_async
         info = torch.empty(3, dtype=torch.int32, device=transp.device)
         getrf_dev_async(panel, transp, info, max_block_size=16)
-        return info[0], info[1]
+        # info[2] = 1: a workgroup of the one-launch base case gave up waiting (the device is shared with other
+        # work) and the panel is partly garbage; pgetrf carries it along and raises at its single host read.
+        return info[0], info[1], info[2]
 
     @staticmethod
     def laswp(a, transp, k0, k1):
@@ -104,9 +106,10 @@ def pgetrf(A, ops=DeviceOps, broadcast=None):
     tdt = _TORCH_OF_KIND[A.kind]
     transp = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
     pbuf = [torch.empty(max(n * nb, 1), dtype=tdt, device=dev) for _ in range(2)]   # factorised panels, contiguous
-    meta = [torch.zeros(nb + 2, dtype=torch.int32, device=dev) for _ in range(2)]  # transpositions, first_zero, nswaps
+    meta = [torch.zeros(nb + 3, dtype=torch.int32, device=dev) for _ in range(2)]  # transpositions, first_zero, nswaps, status
     first_zero = torch.full((), -1, dtype=torch.int32, device=dev)
     nswaps = torch.zeros((), dtype=torch.int32, device=dev)
+    status = torch.zeros((), dtype=torch.int32, device=dev)   # non-zero: some panel's factorisation gave up (see DeviceOps.panel_lu)
     nblocks = (n + nb - 1) // nb
 
     def extent(j):
@@ -118,11 +121,12 @@ def pgetrf(A, ops=DeviceOps, broadcast=None):
         s, owner, rows_p = j & 1, j % P, n - k
         if r == owner:
             mine = A.local.block(k, (j // P) * nb, rows_p, bs)
-            fz, ns = ops.panel_lu(mine, meta[s][:bs])           # transpositions relative to row k
+            fz, ns, *bad = ops.panel_lu(mine, meta[s][:bs])     # transpositions relative to row k
             DeviceMatrix(rows_p, bs, A.kind, ld=max(rows_p, 1), storage=pbuf[s]).as_strided().copy_(mine.as_strided())
             meta[s][:bs] += k
             meta[s][nb] = torch.as_tensor(fz, dtype=torch.int32)
             meta[s][nb + 1] = torch.as_tensor(ns, dtype=torch.int32)
+            meta[s][nb + 2] = torch.as_tensor(bad[0] if bad else 0, dtype=torch.int32)
         if P > 1:
             return [broadcast(pbuf[s][:rows_p * bs], owner), broadcast(meta[s], owner)]
         return []
@@ -150,6 +154,7 @@ def pgetrf(A, ops=DeviceOps, broadcast=None):
         fz = meta[s][nb]
         first_zero = torch.where((first_zero < 0) & (fz >= 0), fz + k, first_zero)
         nswaps = nswaps + meta[s][nb + 1]
+        status = status | meta[s][nb + 2]
         transp[k:k + bs] = meta[s][:bs]
         # local columns left of / right of the panel
         owned_upto_j = (j - r) // P + 1 if r <= j else 0          # local blocks with global index <= j
@@ -166,5 +171,8 @@ def pgetrf(A, ops=DeviceOps, broadcast=None):
         if c_left_end > 0:
             ops.laswp(A.local.block(0, 0, n, c_left_end), transp, k, k + bs)
         apply(j, done_upto, A.nloc)
-    fz_host, ns_host = int(first_zero), int(nswaps)                 # the only wait for the device
+    fz_host, ns_host, bad_host = (int(v) for v in torch.stack([first_zero, nswaps, status]).cpu())  # the only wait for the device
+    if bad_host:
+        raise RuntimeError("pgetrf: a panel's one-launch base case gave up waiting for its workgroups (the device is shared "
+                           "with other work); the factors are not valid. Restore the matrix and run again with EIGAMD_LU_FUSED=0")
     return transp[:n], ns_host, fz_host

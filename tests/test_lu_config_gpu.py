@@ -288,3 +288,57 @@ def test_rowmajor_storage_gives_the_same_factorisation(dt):
         t2, nb2, r2 = ealu.blocked_lu_rowmajor(buf[:, :n])
         assert np.array_equal(t1, t2) and nb1 == nb2 and r1 == r2
         assert np.array_equal(buf[:, :n], col) and (buf[:, n:] == -7.0).all()
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("m,n", [(3000, 3000), (1000, 2000), (2000, 700)])
+def test_device_entry_with_blocks_of_sixteen_on_a_wide_matrix(dt, m, n):
+    """max_block_size = 16 hands the whole matrix to the panel driver: hundreds of 32-column blocks right of a
+    16-column block, far more than a panel of the look-ahead ever has (the one-launch form of the row
+    operations and the rank update keeps a counter per such block and only takes what its counters cover)."""
+    import torch
+    from eigen_amd.device import DeviceMatrix
+    a = eigen_amd.fill_uniform_host(dt, m, n, 1300 + m + n)
+    a1 = a.copy(order="F")
+    t1, nb1, r1 = oracle_lu(a1, max_block=16)
+    d = DeviceMatrix(m, n, eigen_amd.KIND_OF_DTYPE[np.dtype(dt)])
+    d.as_strided().copy_(torch.from_numpy(np.ascontiguousarray(a)))
+    transp, nb2, r2 = ealu.getrf_dev(d, max_block_size=16)
+    a2 = np.asfortranarray(d.as_strided().cpu().numpy())
+    t2 = transp.cpu().numpy()
+    assert r1 == r2 == -1
+    first_diff = check_against_oracle(a, a1, t1, a2, t2, exact_pivots=dt == np.float64)
+    if first_diff is None:
+        assert nb1 == nb2
+
+
+def test_calls_that_do_not_wait_share_the_scratch_in_order():
+    """eigamd_getrf_dev_async returns with its kernels queued; a second factorisation from another stream uses the
+    same per-device scratch (counters, plans, inverses, exchange area) and must run behind the first."""
+    import torch
+    from eigen_amd.device import DeviceMatrix
+    n = 2304
+    mats, want = [], []
+    for i in range(3):
+        a = eigen_amd.fill_uniform_host(np.float64, n, n, 1700 + i)
+        a1 = a.copy(order="F")
+        t1, nb1, r1 = oracle_lu(a1)
+        d = DeviceMatrix(n, n, eigen_amd.F64)
+        d.as_strided().copy_(torch.from_numpy(np.ascontiguousarray(a)))
+        mats.append((a, d))
+        want.append((a1, t1, nb1))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in mats]
+    outs = []
+    for (a, d), s in zip(mats, streams):
+        transp = torch.zeros(n, dtype=torch.int32, device="cuda")
+        info = torch.zeros(3, dtype=torch.int32, device="cuda")
+        ealu.getrf_dev_async(d, transp, info, stream=s)
+        outs.append((transp, info))
+    torch.cuda.synchronize()
+    for (a, d), (a1, t1, nb1), (transp, info) in zip(mats, want, outs):
+        fz, nb2, bad = (int(v) for v in info.cpu())
+        assert (fz, bad) == (-1, 0)
+        a2 = np.asfortranarray(d.as_strided().cpu().numpy())
+        assert check_against_oracle(a, a1, t1, a2, transp.cpu().numpy(), exact_pivots=True) is None
+        assert nb1 == nb2
