@@ -118,6 +118,20 @@ lib.eigamd_trsm_host.restype = ctypes.c_int
 lib.eigamd_trsm_host.argtypes = [ctypes.c_int] * 5 + [_i64, _i64, _vp, _vp, _i64, _vp, _i64]
 lib.eigamd_trsm_dev.restype = ctypes.c_int
 lib.eigamd_trsm_dev.argtypes = [ctypes.c_int] * 5 + [_i64, _i64, _vp, _vp, _i64, _vp, _i64, _vp]
+_i64p = ctypes.POINTER(ctypes.c_int64)
+lib.eigamd_ipc_export.restype = ctypes.c_int
+lib.eigamd_ipc_export.argtypes = [_vp, _vp, _i64p, _i64p]
+lib.eigamd_ipc_open.restype = ctypes.c_int
+lib.eigamd_ipc_open.argtypes = [_vp, ctypes.POINTER(ctypes.c_void_p)]
+lib.eigamd_ipc_close.restype = ctypes.c_int
+lib.eigamd_ipc_close.argtypes = [_vp]
+lib.eigamd_copy_dev_async.restype = ctypes.c_int
+lib.eigamd_copy_dev_async.argtypes = [_vp, _vp, _i64, _vp]
+lib.eigamd_stream_create_cu_mask.restype = ctypes.c_int
+lib.eigamd_stream_create_cu_mask.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+lib.eigamd_stream_destroy.restype = ctypes.c_int
+lib.eigamd_stream_destroy.argtypes = [_vp]
+IPC_HANDLE_BYTES = 64
 _pp = ctypes.POINTER(ctypes.c_void_p)
 lib.eigamd_pgemm_host.restype = ctypes.c_int
 lib.eigamd_pgemm_host.argtypes = [ctypes.c_int] * 3 + [_i64] * 3 + [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, ctypes.c_int,

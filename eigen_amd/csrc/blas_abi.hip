@@ -196,6 +196,13 @@ struct Staging {
   hipEvent_t uploaded = nullptr, computed = nullptr, computed2 = nullptr;  // computed / computed2: the two column panels in flight
   int up_next = 0, down_next = 0;
   CopyPool* pool = nullptr;
+  // Blocks on their way back that download_queue has started and not yet copied out of their pinned chunk.
+  struct PendingDown {
+    bool active = false;
+    char* host = nullptr;
+    int64_t ld = 0, rows = 0, cols = 0;
+    int es = 0;
+  } pending[2];
   int reserve(int i, size_t bytes) {
     if (bytes <= cap[i]) return EIGAMD_OK;
     if (buf[i]) { HIP_TRY(hipFree(buf[i])); buf[i] = nullptr; cap[i] = 0; }
@@ -254,10 +261,50 @@ struct Staging {
     return EIGAMD_OK;
   }
 
+  // A block that fits one pinned chunk starts its way back and the call returns: the DMA of this block runs while
+  // the threads copy the block queued before it out of the other chunk (a walk over many blocks that waited for
+  // each one paid a DMA and a copy per block, one after the other).  download_flush() brings the last ones home.
+  int download_finish(int i) {
+    PendingDown& p = pending[i];
+    if (!p.active) return EIGAMD_OK;
+    HIP_TRY(hipEventSynchronize(down_ready[i]));
+    const size_t colbytes = (size_t)p.rows * p.es;
+    copy_columns(p.host, (size_t)p.ld * p.es, static_cast<const char*>(down[i]), colbytes, colbytes, p.cols);
+    p.active = false;
+    return EIGAMD_OK;
+  }
+  int download_flush() {
+    int rc = download_finish(down_next);       // the older of the two
+    if (rc == EIGAMD_OK) rc = download_finish(down_next ^ 1);
+    return rc;
+  }
+  int download_queue(void* host, int64_t ld, const void* dev, int64_t dld, int64_t rows, int64_t cols, int es) {
+    if (rows <= 0 || cols <= 0) return EIGAMD_OK;
+    const size_t colbytes = (size_t)rows * es;
+    int rc;
+    if (colbytes * (size_t)cols > kChunk) {
+      if ((rc = download_flush()) != EIGAMD_OK) return rc;
+      return download(host, ld, dev, dld, rows, cols, es);
+    }
+    const int i = down_next;
+    down_next ^= 1;
+    if ((rc = download_finish(i)) != EIGAMD_OK) return rc;
+    HIP_TRY(hipMemcpy2DAsync(down[i], colbytes, dev, dld * es, colbytes, cols, hipMemcpyDeviceToHost, d2h));
+    HIP_TRY(hipEventRecord(down_ready[i], d2h));
+    pending[i].active = true;
+    pending[i].host = static_cast<char*>(host);
+    pending[i].ld = ld; pending[i].rows = rows; pending[i].cols = cols; pending[i].es = es;
+    return download_finish(i ^ 1);
+  }
+
   // The reverse, on the d2h stream; returns when the data is in the caller's memory.  The DMA
   // of chunk c+1 runs while the threads copy chunk c out of its pinned buffer.
   int download(void* host, int64_t ld, const void* dev, int64_t dld, int64_t rows, int64_t cols, int es, int64_t inc = 1) {
     if (rows <= 0 || cols <= 0) return EIGAMD_OK;
+    {
+      const int rc0 = download_flush();   // (the chunks are about to be reused)
+      if (rc0 != EIGAMD_OK) return rc0;
+    }
     const size_t colbytes = (size_t)rows * es;
     if (colbytes > kChunk) {
       if (inc != 1) return fail(EIGAMD_ERR_ARG, "a strided column above 64 MiB is not supported");
@@ -506,7 +553,10 @@ int gemm_host_impl(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t k,
   // the reference splits one over the cores without the caller noticing (parallelize_gemm,
   // Eigen/src/Core/products/Parallelizer.h:101-176).
   if (c_inc == 1 && k > 0) {
-    const MultiGpuRule rule = multi_gpu_rule();
+    MultiGpuRule rule = multi_gpu_rule();
+    // Panels of the reduction: the products of the last one run with nothing left to upload beside them, so there
+    // should be at least eight (a 1024-deep local product still runs at nine tenths of a 2048-deep one).
+    if (!getenv("EIGAMD_MULTI_GPU_NB") && k < 8 * rule.nb) rule.nb = 1024;
     if (rule.ranks > 1 && (double)m * (double)n * (double)k >= rule.min_work && m >= 2 * rule.nb && n >= 2 * rule.nb) {
       int nprow = 1;
       for (int r = 1; r * r <= rule.ranks; ++r)
@@ -621,8 +671,8 @@ namespace eigamd {
 int abi_fail(int code, const std::string& what) { return fail(code, what); }  // for the other translation units of the ABI
 
 // rows x cols elements between a caller's (pageable) matrix and memory of the current device, through
-// this device's pinned chunks and copy threads; returns when the data has arrived (an upload with wait = false:
-// once it is queued; staged_upload_wait then waits for all of them).  (Asynchronous 2-D
+// this device's pinned chunks and copy threads; returns when the data has arrived (with wait = false: once it is
+// queued; staged_upload_wait then waits for every upload and brings every queued download home).  (Asynchronous 2-D
 // copies straight from pageable memory, issued on several streams for neighbouring blocks of one host
 // matrix, made the runtime abort now and then; the staged form is also five times faster.)
 int staged_copy(bool to_device, void* dev, int64_t dld, void* host, int64_t ld, int64_t rows, int64_t cols, int es, bool wait) {
@@ -635,6 +685,7 @@ int staged_copy(bool to_device, void* dev, int64_t dld, void* host, int64_t ld, 
     if (wait) HIP_TRY(hipStreamSynchronize(st.h2d));
     return EIGAMD_OK;
   }
+  if (!wait) return st.download_queue(host, ld, dev, dld, rows, cols, es);
   return st.download(host, ld, dev, dld, rows, cols, es);
 }
 int staged_upload_wait() {
@@ -643,7 +694,7 @@ int staged_upload_wait() {
   int rc = st.init();
   if (rc != EIGAMD_OK) return rc;
   HIP_TRY(hipStreamSynchronize(st.h2d));
-  return EIGAMD_OK;
+  return st.download_flush();
 }
 namespace {
 struct EdgeStreams {

@@ -28,7 +28,9 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -42,7 +44,7 @@
 namespace eigamd {
 int abi_fail(int code, const std::string& what);  // blas_abi.hip: sets eigamd_last_error()
 int staged_copy(bool to_device, void* dev, int64_t dld, void* host, int64_t ld, int64_t rows, int64_t cols, int es, bool wait = true);
-int staged_upload_wait();   // until every upload queued so far on the current device's staging handle has landed
+int staged_upload_wait();   // until every copy queued (wait = false) on the current device's staging handle has arrived
 }
 using namespace eigamd;
 
@@ -382,6 +384,23 @@ int move_blocks(eigamd_pgemm& g, int which, char* host, int64_t ld, bool to_devi
 
 bool stored_rows_first(int op) { return op == OP_N || op == OP_CONJ; }
 
+struct HostGridCache {
+  std::mutex mu;
+  eigamd_pgemm* g = nullptr;
+  std::vector<int64_t> key;
+  std::vector<int> devs;
+};
+HostGridCache& host_grid_cache() {
+  static HostGridCache c;
+  return c;
+}
+void release_host_grid() {
+  HostGridCache& c = host_grid_cache();
+  std::lock_guard<std::mutex> l(c.mu);
+  if (c.g) eigamd_pgemm_destroy(c.g);
+  c.g = nullptr;
+}
+
 // The copy streams start behind whatever filled the local parts, on every rank (a piece is read on its
 // owner's device by every receiver).
 int run_prologue(eigamd_pgemm& g) {
@@ -582,8 +601,35 @@ int eigamd_pgemm_host(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t
                       int64_t nb, const int* devices, int transport) {
   if (m == 0 || n == 0) return EIGAMD_OK;
   if (!alpha || !beta || !c || (k > 0 && (!a || !b))) return abi_fail(EIGAMD_ERR_ARG, "invalid pgemm_host arguments");
-  eigamd_pgemm* g = nullptr;
-  PG_TRY(eigamd_pgemm_create(dtype, opa, opb, m, n, k, nprow, npcol, nb, devices, transport, &g));
+  const bool trace = getenv("EIGAMD_PGEMM_TRACE") != nullptr;   // where the wall time of the call goes, on stderr
+  const auto t_start = std::chrono::steady_clock::now();
+  auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+  // One call at a time; the grid of the last call is kept (its streams, events and device memory cost about
+  // 12 ms to set up and tear down at 8192^3, a sixth of the call) and serves the next call of the same shape.
+  HostGridCache& cache = host_grid_cache();
+  std::lock_guard<std::mutex> cache_lock(cache.mu);
+  std::vector<int> key_devs;
+  for (int i = 0; i < nprow * npcol && devices; ++i) key_devs.push_back(devices[i]);
+  const std::vector<int64_t> key = {dtype, opa, opb, m, n, k, nprow, npcol, nb, transport};
+  if (cache.g && (cache.key != key || cache.devs != key_devs)) {
+    eigamd_pgemm_destroy(cache.g);
+    cache.g = nullptr;
+  }
+  if (!cache.g) {
+    PG_TRY(eigamd_pgemm_create(dtype, opa, opb, m, n, k, nprow, npcol, nb, devices, transport, &cache.g));
+    cache.key = key;
+    cache.devs = key_devs;
+    static const int registered = std::atexit(release_host_grid);
+    (void)registered;
+  }
+  eigamd_pgemm* g = cache.g;
+  for (Rank& r : g->ranks)   // a fresh run: no slot holds a piece, nobody is reading one
+    for (int s2 = 0; s2 < 2; ++s2) r.slot_used[s2] = r.a_fetched_set[s2] = r.b_fetched_set[s2] = false;
+  auto drop_grid = [&]() {   // after a failure: the next call starts from a new grid
+    (void)eigamd_pgemm_sync(g);
+    eigamd_pgemm_destroy(g);
+    cache.g = nullptr;
+  };
   double al[2], be[2];
   read_scalars(dtype, alpha, beta, al, be);
   const bool beta_is_zero = be[0] == 0.0 && be[1] == 0.0;
@@ -594,7 +640,7 @@ int eigamd_pgemm_host(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t
     if (rc == EIGAMD_OK) rc = eigamd_pgemm_run(g, alpha, beta);
     if (rc == EIGAMD_OK) rc = eigamd_pgemm_sync(g);
     if (rc == EIGAMD_OK) rc = eigamd_pgemm_gather(g, 2, c, ldc);
-    eigamd_pgemm_destroy(g);
+    if (rc != EIGAMD_OK) drop_grid();
     return rc;
   }
   std::vector<int> devs;
@@ -630,6 +676,7 @@ int eigamd_pgemm_host(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t
         ++sh.landed[(size_t)p];
       }
       sh.cv.notify_all();
+      if (trace) fprintf(stderr, "pgemm_host: device %d panel %lld landed at %.2f ms\n", dev, (long long)p, since());
     }
     {
       std::unique_lock<std::mutex> l(sh.mu);
@@ -641,9 +688,13 @@ int eigamd_pgemm_host(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t
         fail_with(abi_fail(EIGAMD_ERR_DEVICE, "waiting for a device's last product failed"));
         return;
       }
-    const int e = move_blocks(*g, 2, ch, ldc, false, dev);
+    if (trace) fprintf(stderr, "pgemm_host: device %d products done at %.2f ms\n", dev, since());
+    int e = move_blocks(*g, 2, ch, ldc, false, dev, -1, false);
+    if (e == EIGAMD_OK) e = staged_upload_wait();
     if (e != EIGAMD_OK) fail_with(e);
+    if (trace) fprintf(stderr, "pgemm_host: device %d C back at %.2f ms\n", dev, since());
   };
+  if (trace) fprintf(stderr, "pgemm_host: grid %dx%d created at %.2f ms\n", nprow, npcol, since());
   std::vector<std::thread> threads;
   for (int d : devs) threads.emplace_back(device_thread, d);
   const double one[2] = {1.0, 0.0};
@@ -670,8 +721,9 @@ int eigamd_pgemm_host(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t
   sh.cv.notify_all();
   for (std::thread& t : threads) t.join();
   if (rc == EIGAMD_OK) rc = sh.rc;
-  (void)eigamd_pgemm_sync(g);
-  eigamd_pgemm_destroy(g);
+  if (rc == EIGAMD_OK) rc = eigamd_pgemm_sync(g);
+  if (rc != EIGAMD_OK) drop_grid();
+  if (trace) fprintf(stderr, "pgemm_host: done at %.2f ms\n", since());
   return rc;
 }
 

@@ -139,6 +139,31 @@ int eigamd_pgemm_local(eigamd_pgemm* handle, int which, int rank, void** ptr, in
                        int* device);
 int eigamd_pgemm_destroy(eigamd_pgemm* handle);
 
+/* ---- one process per GPU: reading a panel piece out of another process's HBM ----------------
+ * The threads of the reference's parallel product all read ONE packed panel of A
+ * (Eigen/src/Core/products/GeneralMatrixMatrix.h:100-136: blocking.blockA() is shared,
+ * GemmParallelInfo::sync / users say when a slice may be read, Parallelizer.h:81-99).  Between
+ * processes that own one GPU each, "shared" is device memory opened through an inter-process handle
+ * and a read is a device-to-device copy on a copy stream (DMA engines over the xGMI link of the two
+ * devices, no compute unit).  Used by the one-process-per-GPU drivers (eigen_amd/summa.py, plu.py).
+ *
+ * eigamd_ipc_export: handle (EIGAMD_IPC_HANDLE_BYTES bytes) of the allocation `d_ptr` lies in, the
+ * offset of `d_ptr` inside it and the allocation's size; eigamd_ipc_open (in another process): the
+ * allocation's base address in this process; eigamd_ipc_close undoes it.  eigamd_copy_dev_async:
+ * `bytes` bytes between any two device addresses valid in this process, asynchronous on `stream`.
+ *
+ * eigamd_stream_create_cu_mask: a stream whose kernels run on a subset of the compute units, the same
+ * number from every XCD: with leave_free = n on all but n of them, with take_free = n on exactly those
+ * n (rounded up to a multiple of 8).  The local products of the RCCL transport run on the first kind,
+ * so that the compute units a broadcast kernel needs are never all held by product workgroups. */
+#define EIGAMD_IPC_HANDLE_BYTES 64
+int eigamd_ipc_export(const void* d_ptr, void* handle, int64_t* offset, int64_t* span);
+int eigamd_ipc_open(const void* handle, void** d_base);
+int eigamd_ipc_close(void* d_base);
+int eigamd_copy_dev_async(void* d_dst, const void* d_src, int64_t bytes, void* stream);
+int eigamd_stream_create_cu_mask(int leave_free, int take_free, void** stream);
+int eigamd_stream_destroy(void* stream);
+
 /* ---- synthetic operands ------------------------------------------------------
  * U[-1,1) entries from a counter-based generator: element (i,j) depends only on
  * (seed, i, j), so host and device produce bit-identical matrices without a

@@ -28,7 +28,7 @@ def _bcast():
     return device_broadcast if os.environ.get("EIGAMD_TEST_DEVICE_BCAST") else host_staged_broadcast
 
 
-def _worker(rank, world, port, kind, n, nb):
+def _worker(rank, world, port, kind, n, nb, transport=None):
     import faulthandler
     import sys
     faulthandler.dump_traceback_later(90, exit=True)  # a stuck rank reports where, then exits
@@ -51,9 +51,21 @@ def _worker(rank, world, port, kind, n, nb):
         a, b, c0 = rng_np.matrix(dt, 1, n, n), rng_np.matrix(dt, 2, n, n), rng_np.matrix(dt, 3, n, n)
         # the distributed generator reproduces the single-device matrix
         assert np.array_equal(A.local.to_numpy(), a[np.ix_(A.global_rows(), A.global_cols())])
+        stats = None
         for step in range(2):   # two accumulating steps, as bench.py runs them
-            pgemm(1.0, A, B, 1.0, C, broadcast=_bcast())
+            if transport:
+                from eigen_amd.transport import PanelStats
+                stats = PanelStats()
+                pgemm(1.0, A, B, 1.0, C, transport=transport, stats=stats)
+            else:
+                pgemm(1.0, A, B, 1.0, C, broadcast=_bcast())
         torch.cuda.synchronize()
+        if stats is not None:
+            t = stats.summary()
+            assert t["panels"] == (n + nb - 1) // nb and t["compute_ms"] > 0.0
+            if rank == 0:
+                print(f"[{transport}, {world} ranks on one GPU] copy stream {t['comm_ms']} ms, products {t['compute_ms']} ms, "
+                      f"exposed wait {t['exposed_wait_ms']} ms over {t['panels']} panels")
         want = c0.astype(np.complex128) + 2 * (a.astype(np.complex128) @ b.astype(np.complex128))
         got = C.local.to_numpy()
         ref = want[np.ix_(C.global_rows(), C.global_cols())]
@@ -68,6 +80,13 @@ def _worker(rank, world, port, kind, n, nb):
 @pytest.mark.parametrize("world", [2, 4])
 def test_pgemm_real_local_gemm(world):
     mp.spawn(_worker, args=(world, _free_port(), 1, 1024, 128), nprocs=world, join=True)
+
+
+@pytest.mark.parametrize("world,kind,n,nb", [(2, 1, 1024, 128), (4, 1, 1536, 256), (4, 3, 640, 64), (3, 0, 900, 100), (4, 1, 1100, 128)])
+def test_pgemm_pull_transport_between_processes(world, kind, n, nb):
+    """Every receiver copies the panel piece out of the owner's HBM (inter-process memory handles, a copy stream
+    per process): the transport of the one-process-per-GPU driver, here with the processes sharing one GPU."""
+    mp.spawn(_worker, args=(world, _free_port(), kind, n, nb, "ipc"), nprocs=world, join=True)
 
 
 def _lu_worker(rank, world, port, n):
