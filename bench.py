@@ -7,8 +7,10 @@
       A, B random in [-1,1), C accumulates).
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
       one step = the same product at 65536^3, A/B/C distributed 2-D block-cyclically
-      over the N GPUs (eigen_amd/summa.py: panel broadcasts over RCCL, one local GEMM
-      per k-panel).  Fixed total work => "scaling": "strong".
+      over the N GPUs (eigen_amd/summa.py: panel pieces pulled out of their owners' HBM
+      by the DMA engines, or RCCL broadcasts; one local GEMM per k-panel).  Fixed total
+      work => "scaling": "strong".  The line then carries "multi_gpu": per rank the time
+      on the copy stream, in the local products, and waiting for a panel.
 
 Prints ONE JSON line on rank 0.  `value` is whole-job TFLOP/s (2*n^3*steps / wall
 time, max over ranks, barrier + device synchronize on both sides).  `roofline` is
@@ -397,19 +399,24 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
         args.gpus = world
     # EIGAMD_BENCH_REHEARSAL=1: run the multi-rank code path on fewer GPUs than ranks (ranks
-    # share devices, gloo instead of RCCL, panels through a host copy).  For checking the
-    # driver logic on a one-GPU box only; its numbers mean nothing.
+    # share devices, gloo instead of RCCL for the host-side collectives, panels by the pull
+    # transport).  For checking the driver logic on a one-GPU box only; its numbers mean nothing.
     rehearsal = os.environ.get("EIGAMD_BENCH_REHEARSAL") == "1"
     torch.cuda.set_device(local_rank % torch.cuda.device_count() if rehearsal else local_rank)
     if _lib.lib.eigamd_device_ok() != 1:
         raise SystemExit("bench.py needs an MI355X: " + _lib.lib.eigamd_last_error().decode())
-    bcast = None
+    transport = None
     if world > 1:
         if rehearsal:
-            from eigen_amd.summa import host_staged_broadcast as bcast
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # How panel pieces travel between the ranks (eigen_amd/transport.py): EIGAMD_SUMMA_TRANSPORT = ipc | rccl | auto.
+        # auto takes the pull transport (receivers copy out of the owner's HBM with the DMA engines) when every rank can
+        # open its neighbours' memory, else RCCL broadcasts with the local products on a stream that leaves compute units
+        # free for them.  A rehearsal has no RCCL (its ranks share devices).
+        from eigen_amd import transport as tp
+        transport = "ipc" if rehearsal else tp.choose(None)
 
     def max_over_ranks(x):
         t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
@@ -435,8 +442,18 @@ def main():
         A = DistMatrix(grid, n, n, nb, nb, kind).fill_uniform(1)
         B = DistMatrix(grid, n, n, nb, nb, kind).fill_uniform(2)
         C = DistMatrix(grid, n, n, nb, nb, kind).fill_uniform(3)
-        step = lambda: pgemm(1.0, A, B, 1.0, C, local_gemm=timed, broadcast=bcast)
-        layout = f"2-D block-cyclic {grid.nprow}x{grid.npcol}, block {nb}, SUMMA panel broadcast over RCCL"
+        panel_stats = []
+
+        def step():
+            st = tp.PanelStats() if timed.enabled else None
+            pgemm(1.0, A, B, 1.0, C, local_gemm=timed, transport=transport, stats=st)
+            if st is not None:
+                panel_stats.append(st)
+        how = ("every receiver copies the piece out of its owner's HBM (inter-process memory handles, DMA engines)"
+               if transport == "ipc" else
+               f"RCCL broadcasts on row / column communicators, local products on a stream that leaves "
+               f"{os.environ.get('EIGAMD_SUMMA_RCCL_CUS', '16')} compute units free")
+        layout = f"2-D block-cyclic {grid.nprow}x{grid.npcol}, block {nb}, SUMMA one panel ahead; {how}"
 
     for _ in range(warmup):
         step()
@@ -488,13 +505,32 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
-        _, _, fz = pgetrf(L, broadcast=bcast)
+        _, _, fz = pgetrf(L, transport=transport)
         torch.cuda.synchronize()
         dist.barrier()
         lu_secs = max_over_ranks(time.perf_counter() - t0)
         lu_extra = {f"lu_{args.lu}_f64_seconds": round(lu_secs, 4),
                     f"lu_{args.lu}_f64_tflops": round(2.0 / 3.0 * args.lu ** 3 / lu_secs / 1e12, 2),
                     "lu_layout": f"1-D column block-cyclic over {world} GPUs, block {lu_block_size(args.lu)}"}
+
+    # Where every rank's time went, so that a scaling run explains its own efficiency: time on the copy stream,
+    # time in the local products, and how long the compute stream stood waiting for a panel (HIP events per panel).
+    multi = None
+    if world > 1:
+        mine = {"rank": rank, "device": torch.cuda.current_device(), "comm_ms": 0.0, "compute_ms": 0.0, "exposed_wait_ms": 0.0,
+                "exposed_wait_ms_per_panel_max": []}
+        for st in panel_stats:
+            t = st.summary()
+            for key in ("comm_ms", "compute_ms", "exposed_wait_ms"):
+                mine[key] = round(mine[key] + t[key], 3)
+            w = t["exposed_wait_ms_per_panel"]
+            cur = mine["exposed_wait_ms_per_panel_max"]
+            mine["exposed_wait_ms_per_panel_max"] = [max(a, b) for a, b in zip(w, cur)] if cur else w
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine, group=tp.host_group())
+        multi = {"transport": transport, "ranks": world, "rccl_ranks": world if dist.get_backend() == "nccl" else 0,
+                 "grid": [grid.nprow, grid.npcol], "panels_per_step": (n + nb - 1) // nb, "steps_timed": steps,
+                 "wall_ms": round(elapsed * 1e3, 3), "per_rank": everyone}
 
     ms, fl = timed.summary()
     kernel_tflops = sum(fl) / (sum(ms) * 1e-3) / 1e12 if ms else 0.0
@@ -529,6 +565,8 @@ def main():
                          "launches": len(ms), "avg_launch_ms": round(sum(ms) / max(len(ms), 1), 4),
                          "flops_per_launch": fl[0] if fl else 0},
         }
+        if multi:
+            out["multi_gpu"] = multi
         if lu_extra:
             out["extra"] = lu_extra
         if world == 1:

@@ -89,7 +89,7 @@ def test_pgemm_pull_transport_between_processes(world, kind, n, nb):
     mp.spawn(_worker, args=(world, _free_port(), kind, n, nb, "ipc"), nprocs=world, join=True)
 
 
-def _lu_worker(rank, world, port, n):
+def _lu_worker(rank, world, port, n, transport=None):
     import faulthandler
     import sys
     faulthandler.dump_traceback_later(90, exit=True)
@@ -124,11 +124,10 @@ def _lu_worker(rank, world, port, n):
                     torch.cuda.synchronize()
                     print(f"[rank {rank}] +{time.time() - t0:.2f}s update {a22.rows}x{a22.cols}", flush=True)
                     DeviceOps.gemm_minus(a21, a12, a22)
-        transp, nswaps, fz = pgetrf(A, ops, _bcast())
+        transp, nswaps, fz = pgetrf(A, ops, transport=transport) if transport else pgetrf(A, ops, _bcast())
         torch.cuda.synchronize()
-        # the CPU restatement of blocked_lu on the same matrix: identical pivots, same
-        # factors.  (No single-device GPU factorisation here: its two-stream look-ahead
-        # stalls for minutes when several processes share one card.)
+        # the CPU restatement of blocked_lu on the same matrix: identical pivots, same factors; and the
+        # single-device factorisation of the library, run by every rank beside the others on the shared card
         from test_lu_oracle import oracle_lu
         ref_np = np.asfortranarray(full.copy())
         t1, nb1, fz1 = oracle_lu(ref_np)
@@ -138,6 +137,11 @@ def _lu_worker(rank, world, port, n):
         ref = ref_full.numpy()[:, A.global_cols()]
         got = A.local.to_numpy()
         assert np.abs(got - ref).max() <= 64 * np.finfo(np.float64).eps * n * np.abs(ref).max(), rank
+        from eigen_amd import lu as ealu
+        one = np.asfortranarray(full.copy())
+        t2, nb2, fz2 = ealu.blocked_lu(one)
+        assert np.array_equal(t2, t1) and nb2 == nb1 and fz2 == -1
+        assert np.abs(got - one[:, A.global_cols()]).max() <= 64 * np.finfo(np.float64).eps * n * np.abs(ref).max(), rank
     finally:
         dist.destroy_process_group()
 
@@ -146,3 +150,9 @@ def _lu_worker(rank, world, port, n):
 def test_pgetrf_real_device_steps(world):
     """Distributed LU with the library's own panel / swap / solve / GEMM entry points."""
     mp.spawn(_lu_worker, args=(world, _free_port(), 1024), nprocs=world, join=True)
+
+
+@pytest.mark.parametrize("world,n", [(2, 1024), (3, 1100), (4, 1536)])
+def test_pgetrf_pull_transport_between_processes(world, n):
+    """The same with every panel copied out of its owner's HBM by the receivers (inter-process memory handles)."""
+    mp.spawn(_lu_worker, args=(world, _free_port(), n, "ipc"), nprocs=world, join=True)
