@@ -131,6 +131,64 @@ template <typename S> static void solve_cases(const char* tag, double tol) {
   expect_close(name, g.adjoint().lazyProduct(x).eval(), b, 2000 * tol);
 }
 
+// Scalar factors, negation, conjugation and transposition folded into one product call by blas_traits
+// (Eigen/src/Core/util/BlasUtil.h:404-519): the matrix of test/product_extra.cpp:40-50 (every statement of it,
+// with the same operand shapes), then every pairing of {plain, transposed, adjoint, conjugated} left and right
+// operands with factors on either side, column- and row-major storage.  The expected value is always formed
+// from operands evaluated first, by the coefficient-based lazyProduct, which never reaches a product kernel.
+template <typename S, int Order> static void scalar_factor_cases(const char* tag, double tol) {
+  typedef Matrix<S, Dynamic, Dynamic, Order> Mat;
+  typedef Matrix<S, Dynamic, Dynamic> MatC;
+  char name[128];
+  const int rows = 83, cols = 61;
+  const Mat m1 = Mat::Random(rows, cols), m2 = Mat::Random(rows, cols), square = Mat::Random(rows, rows);
+  Mat m3(rows, cols);
+  const S s1 = internal::random<S>(), s2 = internal::random<S>(), s3 = internal::random<S>();
+  int idx = 0;
+#define FOLDED(EXPR, LHS, RHS)                                                                            \
+  do {                                                                                                    \
+    MatC got_;                                                                                            \
+    got_.noalias() = EXPR;                                                                                \
+    const MatC l_ = (LHS), r_ = (RHS);                                                                    \
+    std::snprintf(name, sizeof name, "%s folded #%d %s", tag, idx++, #EXPR);                              \
+    name[90] = 0;                                                                                         \
+    expect_close(name, got_, l_.lazyProduct(r_).eval(), tol);                                             \
+  } while (0)
+  // test/product_extra.cpp:40-50
+  FOLDED(m1 * m2.adjoint(), m1, m2.adjoint());
+  FOLDED(m1.adjoint() * square.adjoint(), m1.adjoint(), square.adjoint());
+  FOLDED(m1.adjoint() * m2, m1.adjoint(), m2);
+  FOLDED((s1 * m1.adjoint()) * m2, s1 * m1.adjoint(), m2);
+  FOLDED(((s1 * m1).adjoint()) * m2, numext::conj(s1) * m1.adjoint(), m2);
+  FOLDED((-m1.adjoint() * s1) * (s3 * m2), -m1.adjoint() * s1, s3 * m2);
+  FOLDED((s2 * m1.adjoint() * s1) * m2, s2 * m1.adjoint() * s1, m2);
+  FOLDED((-m1 * s2) * s1 * m2.adjoint(), -m1 * s2, s1 * m2.adjoint());
+  FOLDED(m1.adjoint() * (s1 * m2).conjugate(), m1.adjoint(), (s1 * m2).conjugate());
+  // every pairing of the four forms (inner dimension rows or cols as the forms demand)
+  const Mat a = Mat::Random(rows, cols), at = Mat::Random(cols, rows), b = Mat::Random(cols, rows), bt = Mat::Random(rows, cols);
+#define LEFT_FORMS(X) X(a) X(at.transpose()) X(at.adjoint()) X(a.conjugate())
+#define PAIR_WITH(L)                                                        \
+  FOLDED((s1 * L) * (b * s3), s1 * L, b * s3);                              \
+  FOLDED((-L) * (s2 * bt.transpose()), -L, s2 * bt.transpose());            \
+  FOLDED((L * s2) * (-(bt.adjoint())), L * s2, -(bt.adjoint()));            \
+  FOLDED((s3 * L).conjugate().conjugate() * (s1 * b.conjugate()), s3 * L, s1 * b.conjugate());
+  LEFT_FORMS(PAIR_WITH)
+#undef PAIR_WITH
+#undef LEFT_FORMS
+  // the same through the accumulating forms
+  {
+    MatC c0 = MatC::Random(rows, rows), c = c0;
+    c.noalias() += (s1 * a) * (s2 * b);
+    std::snprintf(name, sizeof name, "%s folded C += (s1*A)*(s2*B)", tag);
+    expect_close(name, c, (c0 + MatC(s1 * a).lazyProduct(MatC(s2 * b))).eval(), tol);
+    c = c0;
+    c.noalias() -= (s3 * at.adjoint()) * bt.adjoint().conjugate().conjugate();
+    std::snprintf(name, sizeof name, "%s folded C -= (s3*At^H)*Bt^H", tag);
+    expect_close(name, c, (c0 - MatC(s3 * at.adjoint()).lazyProduct(MatC(bt.adjoint()))).eval(), tol);
+  }
+#undef FOLDED
+}
+
 #ifdef EIGEN_USE_BLAS
 // The other level-3 routines the reference's headers bind under EIGEN_USE_BLAS
 // (TriangularMatrixMatrix_BLAS.h, SelfadjointMatrixMatrix_BLAS.h,
@@ -322,6 +380,13 @@ int main(int argc, char** argv) {
   product_cases<double>("double", 1e-13);
   product_cases<std::complex<float> >("cfloat", 2e-5);
   product_cases<std::complex<double> >("cdouble", 1e-13);
+  scalar_factor_cases<float, ColMajor>("float", 2e-5);
+  scalar_factor_cases<double, ColMajor>("double", 1e-13);
+  scalar_factor_cases<std::complex<float>, ColMajor>("cfloat", 2e-5);
+  scalar_factor_cases<std::complex<double>, ColMajor>("cdouble", 1e-13);
+  scalar_factor_cases<double, RowMajor>("double rowmajor", 1e-13);
+  scalar_factor_cases<std::complex<float>, RowMajor>("cfloat rowmajor", 2e-5);
+  scalar_factor_cases<std::complex<double>, RowMajor>("cdouble rowmajor", 1e-13);
   solve_cases<float>("float", 2e-5);
   solve_cases<double>("double", 1e-13);
   solve_cases<std::complex<float> >("cfloat", 2e-5);

@@ -109,3 +109,44 @@ def test_operator_star_at_16384(binary, scalar):
     assert out.returncode == 0, out.stdout[-500:]
     assert "VERIFIED" in out.stdout and "MISMATCH" not in out.stdout
     assert re.search(r"host-to-host: .* TFLOP/s", out.stdout)
+
+
+def test_dgemm_65536_on_one_gpu_crosses_the_32_bit_element_offset():
+    """The configured multi-GPU size on ONE device (3 x 32 GiB resident, one launch of about 8 s): lda = 65536 fits
+    the ABI's 32-bit dimensions, but an element's offset reaches 2^32 (Eigen's Index is ptrdiff_t,
+    Eigen/src/Core/util/Macros.h:34-36), so every address inside the kernels must be formed in 64 bits.  Parity
+    only: the Netlib test ratio of sampled entries, with rows and columns on both sides of the column where the
+    offset j * lda passes 2^32 (j = 65536) -- and of the entries right at the 2^31 / 2^32 / 2^32 + 2^31 marks."""
+    import torch
+    from eigen_amd.device import DeviceMatrix, gemm_dev
+    free, _ = torch.cuda.mem_get_info()
+    n = 65536
+    if free < 3 * n * n * 8 + (4 << 30):
+        pytest.skip("needs 100 GiB of free HBM")
+    kind = 1
+    a = DeviceMatrix(n, n, kind).fill_uniform(1)
+    b = DeviceMatrix(n, n, kind).fill_uniform(2)
+    c = DeviceMatrix(n, n, kind).fill_uniform(3)
+    gemm_dev("N", "N", 1.0, a, b, 1.0, c)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(65536)
+    # columns on both sides of element offsets 2^30, 2^31 and 2^31 + 2^30 (byte offsets 2^33, 2^34, ...; j = offset / lda)
+    marks = np.array([0, 1, 16383, 16384, 32767, 32768, 49151, 49152, n - 2, n - 1])
+    rows = np.unique(np.concatenate([marks, rng.integers(0, n, 12)]))
+    cols = np.unique(np.concatenate([marks, rng.integers(0, n, 12)]))
+    kk = np.arange(n)
+    a_rows = rng_np.entries(np.float64, 1, rows[:, None], kk[None, :])
+    b_cols = rng_np.entries(np.float64, 2, kk[:, None], cols[None, :])
+    c0 = rng_np.entries(np.float64, 3, rows[:, None], cols[None, :])
+    want = a_rows @ b_cols + c0
+    sub = c.as_strided()[torch.as_tensor(rows, device="cuda")][:, torch.as_tensor(cols, device="cuda")].cpu().numpy()
+    r = ratio(kind, sub, want, 1.0, a_rows, b_cols, 1.0, c0)
+    assert r < RATIO_LIMIT, r
+    # nothing outside the sampled set went astray either: column sums of C against A * (B e) + C0 e would need the host;
+    # instead the device's own checksum: e^T C = (e^T A) B + e^T C0, all of it on the device, to a k * eps bound
+    ones = torch.ones(n, dtype=torch.float64, device="cuda")
+    lhs = ones @ c.as_strided()
+    c.fill_uniform(3)
+    rhs = (ones @ a.as_strided()) @ b.as_strided() + ones @ c.as_strided()
+    scale = (ones @ a.as_strided().abs()) @ b.as_strided().abs() + n
+    assert float(((lhs - rhs).abs() / scale).max()) < 64 * n * np.finfo(np.float64).eps
