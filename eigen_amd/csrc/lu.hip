@@ -216,6 +216,131 @@ __global__ void lu_update(T* __restrict__ P, int64_t ld, int rows, int jbw, int 
   }
 }
 
+// max|x| over the entries a kernel of the inversion writes, folded into one word per inverse: the
+// bit pattern of a non-negative double orders like the number itself (NaN above infinity), so an
+// integer atomicMax does it.  lu_inverse_finish reads and resets the word.
+__device__ __forceinline__ void note_inverse_max(unsigned long long* gmax, double local_abs_max) {
+  unsigned long long b = (unsigned long long)__double_as_longlong(fabs(local_abs_max));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_down(b, off, 64);
+    b = o > b ? o : b;
+  }
+  if ((threadIdx.x & 63) == 0 && b != 0) atomicMax(gmax, b);
+}
+__device__ __forceinline__ double abs_max2(double m, double v) {
+  const double a = fabs(v);
+  return (a > m || a != a) ? a : m;
+}
+
+// ---- the inverse of a panel's unit lower triangle, built while the panel is factorised ---------------------
+//
+// The solve A12 <- inv(L11) A12 behind a panel is one product with the explicit inverse X of the panel's bs x bs
+// unit lower triangle (make_inverse), and X used to be worked out by a chain of five launches between the panel
+// and everything that waits for it (0.11 ms of a 1.6 ms step at 4000 rows).  X can be built row block by row
+// block instead, as the panel's 16-column blocks are finished: rows [i0, i1) of X need rows [0, i1) of L only,
+//     X(i, :) = e_i - sum_{k < i} L(i, k) X(k, :),
+// and those rows of L are final once block i / 16 has been factorised and its transpositions have reached the
+// columns to its left.  A few extra workgroups of the next block's base-case launch do it (that launch spends 50 us
+// and more on its sixteen exchanges, the rows take less); what remains behind the panel is the last 16 rows and the
+// look at max|X| (lu_inverse_rows, lu_inverse_tail: two short launches).
+template <typename T> struct InvJob {
+  const T* L = nullptr;   // the bs x bs block (unit lower triangle), leading dimension ldl
+  int64_t ldl = 0;
+  T* X = nullptr;         // bs x bs, leading dimension bs
+  T* XT = nullptr;        // the transpose of X (scratch of the job: what it reads back is contiguous along its lanes)
+  unsigned long long* gmax = nullptr;
+  int bs = 0, i0 = 0, i1 = 0;   // rows [i0, i1) are to be formed; rows [0, i0) are there
+};
+// A job is dealt over kInvGroups workgroups of 256 threads, 64 columns of X each: lane = column, wavefront = four of
+// the sixteen rows of a row block.  With M = E - L(rows, above) X(above, :) the rows are X(rows, :) = inv(L(rows, rows)) M:
+// the sums over the rows above are independent of each other, the 16 x 16 triangle is inverted once by 16 threads.
+constexpr int kInvGroups = 4, kInvChunk = 64;
+template <typename T> struct InvShared {
+  T l[kInvChunk][kMaxBase + 1];    // l[kk][i] = L(r0 + i, k0 + kk); afterwards m[j][lane] in the same memory
+  T d[kMaxBase][kMaxBase + 1];     // d[kk][i] = L(r0 + i, r0 + kk), i > kk
+  T inv[kMaxBase][kMaxBase + 1];   // inv[j][i] = inv(L(rows, rows))(i, j)
+};
+static_assert(kInvChunk * (kMaxBase + 1) >= kMaxBase * 65, "m (16 x 65) lives where l was");
+
+template <typename T, int BATCH = 8> __device__ __forceinline__ void inverse_rows_job(const InvJob<T> job, const int group, InvShared<T>& sh) {
+  const int t = threadIdx.x, cl = t & 63, rg = t >> 6;
+  const int bs = job.bs;
+  const int c0 = group * 64, c = c0 + cl;
+  const T* __restrict__ L = job.L;
+  const int64_t ldl = job.ldl;
+  T* m = &sh.l[0][0];   // m[j * 65 + lane]
+  double mx = 0.0;
+  if (c0 < bs) {   // (uniform: a group beyond the block has nothing to do)
+  for (int r0 = job.i0; r0 < job.i1; r0 += kMaxBase) {
+    const int nr = min(kMaxBase, job.i1 - r0);
+    T acc[4] = {(T)0, (T)0, (T)0, (T)0};
+    // the rows above: X(k, c) = 0 for k < c, so k starts at this group's first column
+    for (int k0 = c0; k0 < r0; k0 += kInvChunk) {
+      __syncthreads();
+      for (int idx = t; idx < kInvChunk * kMaxBase; idx += 256) {
+        const int i = idx % kMaxBase, kk = idx / kMaxBase;
+        sh.l[kk][i] = (i < nr && k0 + kk < r0) ? L[(r0 + i) + (int64_t)(k0 + kk) * ldl] : (T)0;
+      }
+      __syncthreads();
+      if (c < bs) {
+        // BATCH loads in flight per thread.  (8 where the job shares its kernel, and that kernel's register budget, with a
+        // base case; the launch behind the panel, which stands between the panel and the next one, takes 32.)
+#pragma unroll 1
+        for (int h = 0; h < kInvChunk; h += BATCH) {
+          T xk[BATCH];
+#pragma unroll
+          for (int u = 0; u < BATCH; ++u) xk[u] = k0 + h + u < r0 ? job.XT[c + (int64_t)(k0 + h + u) * bs] : (T)0;
+#pragma unroll
+          for (int u = 0; u < BATCH; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] += sh.l[h + u][4 * rg + q] * xk[u];
+        }
+      }
+    }
+    __syncthreads();
+    // the triangle on the diagonal and its inverse (thread j: column j, by substitution)
+    for (int idx = t; idx < kMaxBase * kMaxBase; idx += 256) {
+      const int i = idx % kMaxBase, kk = idx / kMaxBase;
+      sh.d[kk][i] = (i < nr && kk < i) ? L[(r0 + i) + (int64_t)(r0 + kk) * ldl] : (T)0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) m[(4 * rg + q) * 65 + cl] = ((r0 + 4 * rg + q == c) ? (T)1 : (T)0) - acc[q];
+    __syncthreads();
+    if (t < kMaxBase) {   // column t of the triangle's inverse, kept in LDS as it grows (no register array: see above)
+#pragma unroll 1
+      for (int i = 0; i < kMaxBase; ++i) {
+        T v = i == t ? (T)1 : (T)0;
+#pragma unroll 1
+        for (int kk = t; kk < i; ++kk) v -= sh.d[kk][i] * sh.inv[t][kk];
+        sh.inv[t][i] = i < t ? (T)0 : v;
+      }
+    }
+    __syncthreads();
+    if (c < bs) {
+      T v[4] = {(T)0, (T)0, (T)0, (T)0};
+#pragma unroll 1
+      for (int j = 0; j < kMaxBase; ++j) {   // (inv[j][i] = 0 for i < j)
+        const T mj = m[j * 65 + cl];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += sh.inv[j][4 * rg + q] * mj;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = 4 * rg + q;
+        if (i < nr) {
+          job.X[(r0 + i) + (int64_t)c * bs] = v[q];
+          job.XT[c + (int64_t)(r0 + i) * bs] = v[q];
+          mx = abs_max2(mx, (double)v[q]);
+        }
+      }
+    }
+    __syncthreads();   // (the next row block reads these rows of XT back: same workgroup)
+  }
+  }
+  note_inverse_max(job.gmax, mx);
+}
+
 // ---- the base case in one kernel ---------------------------------------------------
 //
 // The workgroups of the fused base case agree on each pivot through an exchange area in
@@ -316,13 +441,20 @@ template <typename T>
 __global__ void __launch_bounds__(kRowsPerBlock, 4)
     lu_base_fused(T* __restrict__ P, int64_t ld, int rows, int jbw, int size, int* __restrict__ transp,
                   int row_offset, int col_global, BaseSlot<T>* __restrict__ slots, BaseTop<T>* __restrict__ tops,
-                  unsigned gen0, int* __restrict__ error, int* __restrict__ first_zero, int* __restrict__ nswaps) {
+                  unsigned gen0, int* __restrict__ error, int* __restrict__ first_zero, int* __restrict__ nswaps, InvJob<T> job) {
   __shared__ T s_u[kMaxBase];
   __shared__ T s_top[kMaxBase];
   __shared__ unsigned s_pub[kRowsPerBlock / 64][kMaxBase * Words<T>::N];  // per wavefront: the words of the row it is about to publish
   __shared__ int s_win_row, s_flags;   // the winner's row; 1: the pivot is exactly zero, 2: gave up waiting
   constexpr int NW = Words<T>::N;
-  const int nparts = gridDim.x;
+  // The last workgroups of the grid take no part in the factorisation: rows of the enclosing panel's inverse
+  // (InvJob), which fit into the time the others spend on their sixteen exchanges.
+  const int nparts = (int)gridDim.x - (job.i1 > job.i0 ? kInvGroups : 0);
+  if ((int)blockIdx.x >= nparts) {
+    __shared__ InvShared<T> s_inv;
+    inverse_rows_job<T>(job, (int)blockIdx.x - nparts, s_inv);
+    return;
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = blockIdx.x * kRowsPerBlock + threadIdx.x;
   const bool valid = r < rows;
@@ -543,7 +675,12 @@ constexpr int kSingleThreads = 1024, kSingleRpt = 2, kSingleRows = kSingleThread
 template <typename T>
 __global__ void __launch_bounds__(kSingleThreads)
     lu_base_single(T* __restrict__ P, int64_t ld, int rows, int jbw, int size, int* __restrict__ transp, int row_offset,
-                   int col_global, int* __restrict__ first_zero, int* __restrict__ nswaps) {
+                   int col_global, int* __restrict__ first_zero, int* __restrict__ nswaps, InvJob<T> job) {
+  if (blockIdx.x > 0) {   // rows of the enclosing panel's inverse (InvJob): a job's workgroup has 256 threads
+    __shared__ InvShared<T> s_inv;
+    if (threadIdx.x < 256) inverse_rows_job<T>(job, (int)blockIdx.x - 1, s_inv);
+    return;
+  }
   __shared__ T s_u[kMaxBase];
   __shared__ T s_top[kMaxBase];
   __shared__ T s_val[kSingleThreads / 64];
@@ -1044,23 +1181,6 @@ __global__ void lu_trsm_small(const T* __restrict__ L, int64_t ldl, T* __restric
     if (i < jb) col[i] = x[i];
 }
 
-// max|x| over the entries a kernel of the inversion writes, folded into one word per inverse: the
-// bit pattern of a non-negative double orders like the number itself (NaN above infinity), so an
-// integer atomicMax does it.  lu_inverse_finish reads and resets the word.
-__device__ __forceinline__ void note_inverse_max(unsigned long long* gmax, double local_abs_max) {
-  unsigned long long b = (unsigned long long)__double_as_longlong(fabs(local_abs_max));
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const unsigned long long o = __shfl_down(b, off, 64);
-    b = o > b ? o : b;
-  }
-  if ((threadIdx.x & 63) == 0 && b != 0) atomicMax(gmax, b);
-}
-__device__ __forceinline__ double abs_max2(double m, double v) {
-  const double a = fabs(v);
-  return (a > m || a != a) ? a : m;
-}
-
 // X = L^-1 for the unit lower triangle L of a bs x bs block (bs <= kPlanSpan), written as a
 // full bs x bs matrix (zeros above the diagonal) with leading dimension bs.  A workgroup
 // owns 32 columns of X, kept in LDS, and walks down the rows 32 at a time: first the part of
@@ -1331,6 +1451,28 @@ __global__ void __launch_bounds__(256) lu_inverse_finish(T* __restrict__ X, int 
     for (int idx = threadIdx.x; idx < bs * bs; idx += 256) X[idx] = (idx % bs == idx / bs) ? (T)1 : (T)0;
 }
 
+// What is left of the inverse behind the panel: its last rows (lu_inverse_rows, kInvGroups workgroups), then the look
+// at max|X| (lu_inverse_tail, as lu_inverse_finish).
+template <typename T>
+__global__ void __launch_bounds__(256) lu_inverse_rows(InvJob<T> job) {
+  __shared__ InvShared<T> s_inv;
+  inverse_rows_job<T, 32>(job, (int)blockIdx.x, s_inv);
+}
+template <typename T>
+__global__ void __launch_bounds__(256) lu_inverse_tail(InvJob<T> job, double limit, int* __restrict__ flag) {
+  __shared__ int s_subst;
+  if (threadIdx.x == 0) {
+    const unsigned long long b = __hip_atomic_load(job.gmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double mx = __longlong_as_double((long long)b);
+    __hip_atomic_store(job.gmax, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next inversion that uses this word
+    s_subst = !(mx <= limit);
+    *flag = s_subst;
+  }
+  __syncthreads();
+  if (s_subst)
+    for (int idx = threadIdx.x; idx < job.bs * job.bs; idx += 256) job.X[idx] = (idx % job.bs == idx / job.bs) ? (T)1 : (T)0;
+}
+
 // B (bs x ncols) <- L^-1 B by substitution, L unit lower (bs <= kPlanSpan), one thread per column,
 // the unknowns 32 at a time: their 32 x 32 triangle from LDS, then one read-modify-write per row below.
 template <typename T>
@@ -1450,6 +1592,14 @@ inline BaseCaseRule read_base_case_rule() {
   return r;
 }
 
+// Where the inverse of a panel's unit lower triangle is to be built while the panel is factorised (InvJob).
+template <typename T> struct InverseTarget {
+  T* X = nullptr;
+  int* flag = nullptr;
+  unsigned long long* gmax = nullptr;
+  T* XT = nullptr;   // scratch for the transpose (InvJob)
+};
+
 template <typename T> struct Workspace {
   Candidate<T>* partials;
   Side<T>* side;
@@ -1470,6 +1620,7 @@ template <typename T> struct Workspace {
   // kPlanSpan-wide piece of the step's block; the last set: blocked() itself (one stream).
   SwapPlan* plan[2 * kMaxSub + 1];
   T* linv[2 * kMaxSub + 1];
+  T* linvT[2 * kMaxSub + 1];        // their transposes while they are built (InvJob)
   int* linv_flag[2 * kMaxSub + 1];  // set by lu_inverse_finish: solve by substitution, linv holds the identity
   unsigned long long* linv_max[2 * kMaxSub + 1];  // max|inv(L)| as the inversion kernels noted it (zero between uses)
   double inverse_limit;
@@ -1481,21 +1632,23 @@ constexpr int kOwnScratch = 2 * kMaxSub;
 // unblocked_lu (PartialPivLU.h:357-412) on the rows x jbw sub-panel at P.
 template <typename T>
 hipError_t unblocked(T* P, int64_t ld, int64_t rows, int jbw, int* transp, int row_offset, int col_offset,
-                     const Workspace<T>& w, hipStream_t s) {
+                     const Workspace<T>& w, hipStream_t s, const InvJob<T>& ride = InvJob<T>()) {
   const int size = (int)std::min<int64_t>(rows, jbw);
   int nparts = (int)((rows + kRowsPerBlock - 1) / kRowsPerBlock);
+  const int njob = ride.i1 > ride.i0 ? kInvGroups : 0;   // extra workgroups at the end of the grid: rows of the panel's inverse
   if (rows <= kSingleRows && w.rule.single) {
-    hipLaunchKernelGGL(lu_base_single<T>, dim3(1), dim3(kSingleThreads), 0, s, P, ld, (int)rows, jbw, size, transp,
-                       row_offset, col_offset, w.first_zero, w.nswaps);
+    hipLaunchKernelGGL(lu_base_single<T>, dim3(1 + njob), dim3(kSingleThreads), 0, s, P, ld, (int)rows, jbw, size, transp,
+                       row_offset, col_offset, w.first_zero, w.nswaps, ride);
     return hipGetLastError();
   }
-  if (nparts <= w.fused_capacity && w.rule.fused) {
+  if (nparts + njob <= w.fused_capacity && w.rule.fused) {
     const unsigned gen0 = *w.generation;
     *w.generation += (unsigned)size;
-    hipLaunchKernelGGL(lu_base_fused<T>, dim3(nparts), dim3(kRowsPerBlock), 0, s, P, ld, (int)rows, jbw, size, transp,
-                       row_offset, col_offset, w.slots, w.tops, gen0, w.error, w.first_zero, w.nswaps);
+    hipLaunchKernelGGL(lu_base_fused<T>, dim3(nparts + njob), dim3(kRowsPerBlock), 0, s, P, ld, (int)rows, jbw, size, transp,
+                       row_offset, col_offset, w.slots, w.tops, gen0, w.error, w.first_zero, w.nswaps, ride);
     return hipGetLastError();
   }
+  if (njob) hipLaunchKernelGGL(lu_inverse_rows<T>, dim3(kInvGroups), dim3(256), 0, s, ride);
   hipLaunchKernelGGL(lu_colmax<T>, dim3(nparts), dim3(kRowsPerBlock), 0, s, P, ld, 0, (int)rows, 0, w.partials);
   for (int jj = 0; jj < size; ++jj) {
     hipLaunchKernelGGL(lu_pivot<T>, dim3(1), dim3(64), 0, s, P, ld, jbw, jj, w.partials, nparts, transp + jj, row_offset,
@@ -1581,6 +1734,13 @@ hipError_t make_inverse(const T* L, int64_t ldl, int64_t bs, T* X, int* flag, un
   hipLaunchKernelGGL(lu_inverse_finish<T>, dim3(1), dim3(256), 0, s, X, (int)bs, limit, gmax, flag);
   return hipGetLastError();
 }
+inline bool incremental_inverse_enabled() {   // EIGAMD_LU_INVERSE_ON_THE_WAY=0: the chain of launches behind the panel (make_inverse)
+  static const bool on = [] {
+    const char* e = std::getenv("EIGAMD_LU_INVERSE_ON_THE_WAY");
+    return !(e && std::atoi(e) == 0);
+  }();
+  return on;
+}
 template <typename T> bool inverse_applies(int64_t bs) { return bs > 32 && bs <= kPlanSpan && bs <= gemm_tile_rows<T>(); }
 template <typename T>
 hipError_t apply_inverse(const T* X, const int* flag, const T* L, int64_t ldl, int64_t bs, T* B, int64_t ldb, int64_t ncols,
@@ -1595,9 +1755,13 @@ hipError_t apply_inverse(const T* X, const int* flag, const T* L, int64_t ldl, i
 // blocked_lu (PartialPivLU.h:429-498).  A points at the (row0, row0) corner of the
 // enclosing matrix `base`; transposition entries are written as GLOBAL row indices of
 // `base`, so the caller-level "+= k" of the reference (:481) is already applied.
+// `inv`: at the level of a panel (blocks of 16) the inverse of the panel's triangle is built into inv[0] on the way
+// (complete, with its flag, when the call returns); at a level above, inv[i] is the target of the i-th panel of
+// this level (null: the scratch of blocked() itself), which the solve behind that panel then uses.
 template <typename T>
 hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows, int64_t cols, int* transp,
-                   int64_t max_block, const Workspace<T>& w, hipStream_t s, int64_t force_block = 0) {
+                   int64_t max_block, const Workspace<T>& w, hipStream_t s, int64_t force_block = 0,
+                   const InverseTarget<T>* inv = nullptr, InvJob<T> ride = InvJob<T>()) {
   T* A = base + row0 + col0 * ld;
   const int64_t size = std::min(rows, cols);
   if (size <= kMaxBase) {
@@ -1605,7 +1769,7 @@ hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows
     // leading rows x rows part and bring the columns to its right up to date with the same
     // operations in the same order: the recorded swaps, then forward substitution.
     const int jbw = (int)std::min<int64_t>(cols, rows);
-    LU_TRY(unblocked<T>(A, ld, rows, jbw, transp + row0, (int)row0, (int)col0, w, s));
+    LU_TRY(unblocked<T>(A, ld, rows, jbw, transp + row0, (int)row0, (int)col0, w, s, ride));
     if (cols > jbw) {
       LU_TRY(laswp<T>(base + (col0 + jbw) * ld, ld, cols - jbw, transp, (int)row0, (int)(row0 + jbw), w.plan[kOwnScratch], s));
       hipLaunchKernelGGL((lu_trsm_small<T, kMaxBase>), dim3((unsigned)((cols - jbw + 63) / 64)), dim3(64), 0, s, A, ld,
@@ -1614,11 +1778,28 @@ hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows
     return hipGetLastError();
   }
   const int64_t block = force_block > 0 ? force_block : block_size_rule(size, max_block);
+  // (panel level) rows of the inverse that are there; the job of a launch: the rows whose part of L is final by then
+  const bool build_inverse = inv != nullptr && block <= kMaxBase && inverse_applies<T>(size);
+  int64_t x_done = 0;
+  auto inverse_job = [&](int64_t upto) {
+    InvJob<T> job;
+    if (build_inverse && upto > x_done) {
+      job.L = A; job.ldl = ld; job.X = inv[0].X; job.XT = inv[0].XT; job.gmax = inv[0].gmax;
+      job.bs = (int)size; job.i0 = (int)x_done; job.i1 = (int)upto;
+      x_done = upto;
+    }
+    return job;
+  };
+  const InverseTarget<T> own = {w.linv[kOwnScratch], w.linv_flag[kOwnScratch], w.linv_max[kOwnScratch], w.linvT[kOwnScratch]};
   for (int64_t k = 0; k < size; k += block) {
     const int64_t bs = std::min(size - k, block);
     const int64_t trows = rows - k - bs, tsize = size - k - bs;
-    // the panel [A11; A21], recursively with blocks of 16 (:472-473)
-    LU_TRY(blocked<T>(base, ld, row0 + k, col0 + k, trows + bs, bs, transp, 16, w, s));
+    const InverseTarget<T>& target = (block > kMaxBase && inv != nullptr) ? inv[k / block] : own;
+    const bool inverted_on_the_way = block > kMaxBase && trows > 0 && inverse_applies<T>(bs) && incremental_inverse_enabled();
+    // the panel [A11; A21], recursively with blocks of 16 (:472-473); at panel level the launch of this block's base
+    // case carries the rows of the inverse that belong to the blocks before it (their part of L no longer moves)
+    LU_TRY(blocked<T>(base, ld, row0 + k, col0 + k, trows + bs, bs, transp, 16, w, s, 0, inverted_on_the_way ? &target : nullptr,
+                      inverse_job(k)));
     if (bs <= kMaxBase) {
       // Narrow blocks (inside a panel): the transpositions on both sides (A_0 :479-483, A_2
       // :488-489) and the triangular solve (:492) in one launch, then the rank-bs update (:494).
@@ -1631,9 +1812,9 @@ hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows
       if (w.rank_count && trows > 0 && trows <= w.rank_fused_max && tsize > 0 && ncb <= kRankCounters) {
         const int nrb = (int)((trows + 255) / 256);
         const int nleft_wg = (int)((k + 255) / 256);
-        hipLaunchKernelGGL(lu_rowops_rank_update<T>, dim3((unsigned)(nrb * ncb + nleft_wg)), dim3(256), 0, s, base, ld, transp,
-                           (int)(row0 + k), (int)bs, (int)(col0 + k), (int)(col0 + k + bs), (int)tsize, (int)col0, (int)k,
-                           (int)trows, nrb, ncb, w.rank_count);
+        hipLaunchKernelGGL(lu_rowops_rank_update<T>, dim3((unsigned)(nrb * ncb + nleft_wg)), dim3(256), 0, s,
+                           base, ld, transp, (int)(row0 + k), (int)bs, (int)(col0 + k), (int)(col0 + k + bs), (int)tsize, (int)col0,
+                           (int)k, (int)trows, nrb, ncb, w.rank_count);
         LU_TRY(hipGetLastError());
         continue;
       }
@@ -1644,9 +1825,17 @@ hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows
         LU_TRY(hipGetLastError());
       }
       if (trows && tsize > 0) {
-        hipLaunchKernelGGL(lu_rank_update<T>, dim3((unsigned)((trows + 255) / 256), (unsigned)((tsize + kRankCols - 1) / kRankCols)),
+        hipLaunchKernelGGL(lu_rank_update<T>,
+                           dim3((unsigned)((trows + 255) / 256), (unsigned)((tsize + kRankCols - 1) / kRankCols)),
                            dim3(256), 0, s, A + (k + bs) + k * ld, A + k + (k + bs) * ld, A + (k + bs) + (k + bs) * ld, ld,
                            (int)trows, (int)tsize, (int)bs);
+        LU_TRY(hipGetLastError());
+      }
+      if (build_inverse && k + bs >= size) {   // the panel's last block: what is left of the inverse, and the look at max|X|
+        InvJob<T> job = inverse_job(size);
+        if (job.i1 > job.i0) hipLaunchKernelGGL(lu_inverse_rows<T>, dim3(kInvGroups), dim3(256), 0, s, job);
+        job.X = inv[0].X; job.gmax = inv[0].gmax; job.bs = (int)size;
+        hipLaunchKernelGGL(lu_inverse_tail<T>, dim3(1), dim3(256), 0, s, job, w.inverse_limit, inv[0].flag);
         LU_TRY(hipGetLastError());
       }
       continue;
@@ -1661,8 +1850,8 @@ hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows
       T* A21 = A + (k + bs) + k * ld;
       T* A22 = A + (k + bs) + (k + bs) * ld;
       if (inverse_applies<T>(bs)) {                                    // (:492)
-        LU_TRY(make_inverse<T>(A11, ld, bs, w.linv[kOwnScratch], w.linv_flag[kOwnScratch], w.linv_max[kOwnScratch], w.inverse_limit, s));
-        LU_TRY(apply_inverse<T>(w.linv[kOwnScratch], w.linv_flag[kOwnScratch], A11, ld, bs, A12, ld, tsize, s));
+        if (!inverted_on_the_way) LU_TRY(make_inverse<T>(A11, ld, bs, target.X, target.flag, target.gmax, w.inverse_limit, s));
+        LU_TRY(apply_inverse<T>(target.X, target.flag, A11, ld, bs, A12, ld, tsize, s));
       } else {
         LU_TRY(trsm_unit_lower<T>(A11, A12, ld, bs, tsize, s));
       }
@@ -1786,7 +1975,19 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
     const bool planned = bs > 32;
     LU_TRY(hipStreamWaitEvent(pan, st.ready, 0));
     if (right_recorded[par]) LU_TRY(hipStreamWaitEvent(pan, st.right_done[par], 0));  // (this parity's scratch: step - 2)
-    LU_TRY(blocked<T>(A, ld, k, k, trows + bs, bs, transp, 16, w, pan, bs > rule_block ? rule_block : 0));
+    // The inverted triangles of the step's pieces are built while the pieces are factorised (InvJob), straight into
+    // this step's scratch; EIGAMD_LU_INVERSE_ON_THE_WAY=0: by the chain of launches behind the panel, as before.
+    InverseTarget<T> targets[kMaxSub];
+    for (int i = 0; i < nsub; ++i) targets[i] = {linv[i], linv_flag[i], w.linv_max[par * kMaxSub + i], w.linvT[par * kMaxSub + i]};
+    const bool on_the_way = incremental_inverse_enabled() && trows > 0 && planned;
+    if (bs > rule_block) {
+      LU_TRY(blocked<T>(A, ld, k, k, trows + bs, bs, transp, 16, w, pan, rule_block, on_the_way && rule_block == kPlanSpan ? targets : nullptr));
+    } else {
+      // (one piece: this call is the panel level itself)
+      const bool direct = on_the_way && inverse_applies<T>(bs);
+      LU_TRY(blocked<T>(A, ld, k, k, trows + bs, bs, transp, 16, w, pan, 0, direct ? targets : nullptr));
+    }
+    const bool pieces_inverted = on_the_way && (bs > rule_block ? rule_block == kPlanSpan : true);
     if (planned)
       for (int i = 0; i < nsub; ++i)
         LU_TRY(make_plan(transp, (int)(k + sub_begin(i)), (int)(k + sub_begin(i) + sub_size(i)), plan[i], pan));
@@ -1795,7 +1996,7 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
     // the panel and everything that follows it).
     LU_TRY(hipEventRecord(st.factored, pan));
     LU_TRY(hipStreamWaitEvent(upd, st.factored, 0));
-    if (trows > 0)
+    if (trows > 0 && !pieces_inverted)
       for (int i = 0; i < nsub; ++i)
         if (inverse_applies<T>(sub_size(i)))
           LU_TRY(make_inverse<T>(A + (k + sub_begin(i)) * (ld + 1), ld, sub_size(i), linv[i], linv_flag[i], w.linv_max[par * kMaxSub + i], w.inverse_limit, pan));
@@ -2023,7 +2224,8 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   const size_t off_plan = off_slots + 2 * (size_t)kMaxFusedParts * sizeof(BaseSlot<T>);
   constexpr int kSets = 2 * kMaxSub + 1;
   const size_t off_linv = off_plan + kSets * round64(sizeof(SwapPlan));
-  const size_t off_partials = off_linv + kSets * round64((size_t)kPlanSpan * kPlanSpan * sizeof(T));
+  const size_t off_linvT = off_linv + kSets * round64((size_t)kPlanSpan * kPlanSpan * sizeof(T));
+  const size_t off_partials = off_linvT + kSets * round64((size_t)kPlanSpan * kPlanSpan * sizeof(T));
   const size_t need = off_partials + round64(nparts * sizeof(Candidate<T>));
   if (!sc.buf_done) LU_TRY(hipEventCreateWithFlags(&sc.buf_done, hipEventDisableTiming));
   if (sc.buf_busy) {
@@ -2072,6 +2274,7 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   for (int i = 0; i < kSets; ++i) {
     w.plan[i] = reinterpret_cast<SwapPlan*>(p + off_plan + i * round64(sizeof(SwapPlan)));
     w.linv[i] = reinterpret_cast<T*>(p + off_linv + i * round64((size_t)kPlanSpan * kPlanSpan * sizeof(T)));
+    w.linvT[i] = reinterpret_cast<T*>(p + off_linvT + i * round64((size_t)kPlanSpan * kPlanSpan * sizeof(T)));
     w.linv_flag[i] = reinterpret_cast<int*>(p) + 8 + i;
     w.linv_max[i] = reinterpret_cast<unsigned long long*>(p + 128) + i;
   }
