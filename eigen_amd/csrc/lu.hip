@@ -1621,6 +1621,7 @@ template <typename T> struct Workspace {
   SwapPlan* plan[2 * kMaxSub + 1];
   T* linv[2 * kMaxSub + 1];
   T* linvT[2 * kMaxSub + 1];        // their transposes while they are built (InvJob)
+  T* solve_tmp;                     // (kMaxSub kPlanSpan)^2 elements: the solved rows of the next step's columns (see blocked_lookahead)
   int* linv_flag[2 * kMaxSub + 1];  // set by lu_inverse_finish: solve by substitution, linv holds the identity
   unsigned long long* linv_max[2 * kMaxSub + 1];  // max|inv(L)| as the inversion kernels noted it (zero between uses)
   double inverse_limit;
@@ -1734,6 +1735,13 @@ hipError_t make_inverse(const T* L, int64_t ldl, int64_t bs, T* X, int* flag, un
   hipLaunchKernelGGL(lu_inverse_finish<T>, dim3(1), dim3(256), 0, s, X, (int)bs, limit, gmax, flag);
   return hipGetLastError();
 }
+inline bool solve_out_of_place_enabled() {   // EIGAMD_LU_SOLVE_TMP=0: the next step's columns are solved in place
+  static const bool on = [] {
+    const char* e = std::getenv("EIGAMD_LU_SOLVE_TMP");
+    return !(e && std::atoi(e) == 0);
+  }();
+  return on;
+}
 inline bool incremental_inverse_enabled() {   // EIGAMD_LU_INVERSE_ON_THE_WAY=0: the chain of launches behind the panel (make_inverse)
   static const bool on = [] {
     const char* e = std::getenv("EIGAMD_LU_INVERSE_ON_THE_WAY");
@@ -1742,13 +1750,16 @@ inline bool incremental_inverse_enabled() {   // EIGAMD_LU_INVERSE_ON_THE_WAY=0:
   return on;
 }
 template <typename T> bool inverse_applies(int64_t bs) { return bs > 32 && bs <= kPlanSpan && bs <= gemm_tile_rows<T>(); }
+// With `out` the product goes there instead (leading dimension ldo): a product that does not overwrite its operand may
+// run on any tile, and a block of few columns then spreads over many compute units instead of two large tiles.
 template <typename T>
 hipError_t apply_inverse(const T* X, const int* flag, const T* L, int64_t ldl, int64_t bs, T* B, int64_t ldb, int64_t ncols,
-                         hipStream_t s) {
+                         hipStream_t s, T* out = nullptr, int64_t ldo = 0) {
   if (ncols <= 0) return hipSuccess;
   hipLaunchKernelGGL(lu_subst_flagged<T>, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, s, flag, L, ldl, (int)bs, B, ldb,
                      (int)ncols);
   LU_TRY(hipGetLastError());
+  if (out) return gemm_assign<T>(bs, ncols, bs, X, bs, B, ldb, out, ldo, s);
   return gemm_assign<T>(bs, ncols, bs, X, bs, B, ldb, B, ldb, s);
 }
 
@@ -2009,17 +2020,21 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
     };
     // A12 <- L^-1 A12 with L the unit lower triangle of the step's bs x bs block, piece by piece:
     // the piece's own triangle (inverted where that applies), then the rows of the later pieces.
-    auto solve = [&](T* A12, int64_t ncols, hipStream_t q) -> hipError_t {
+    // With `tmp` (bs x ncols, leading dimension bs) the solved rows are written there and A12 keeps the unsolved ones;
+    // the caller multiplies with tmp and copies it over A12 when nothing waits for that any more.
+    auto solve = [&](T* A12, int64_t ncols, hipStream_t q, T* tmp = nullptr) -> hipError_t {
       if (q != pan) LU_TRY(hipStreamWaitEvent(q, st.inverted, 0));
       for (int i = 0; i < nsub; ++i) {
         const int64_t o = sub_begin(i), sb = sub_size(i);
         const T* L = A + (k + o) * (ld + 1);
-        if (inverse_applies<T>(sb)) LU_TRY(apply_inverse<T>(linv[i], linv_flag[i], L, ld, sb, A12 + o, ld, ncols, q));
+        if (inverse_applies<T>(sb)) LU_TRY(apply_inverse<T>(linv[i], linv_flag[i], L, ld, sb, A12 + o, ld, ncols, q, tmp ? tmp + o : nullptr, bs));
         else LU_TRY(trsm_unit_lower<T>(L, A12 + o, ld, sb, ncols, q));
-        if (o + sb < bs) LU_TRY(gemm_minus3<T>(bs - o - sb, ncols, sb, L + sb, ld, A12 + o, ld, A12 + o + sb, ld, q));
+        if (o + sb < bs) LU_TRY(gemm_minus3<T>(bs - o - sb, ncols, sb, L + sb, ld, tmp ? tmp + o : A12 + o, tmp ? bs : ld, A12 + o + sb, ld, q));
       }
       return hipSuccess;
     };
+    bool all_inverted = true;
+    for (int i = 0; i < nsub; ++i) all_inverted = all_inverted && inverse_applies<T>(sub_size(i));
     T* A21 = A + (k + bs) + k * ld;
     const int64_t nb = (trows && tsize > 0) ? width_at(step + 1, tsize) : 0;
     // how the columns [lo, size) right of the next step's block are dealt in this step
@@ -2044,12 +2059,21 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
     }
     // columns of the next step's block first
     if (nb > 0) {
+      // These few columns stand between this panel and the next one.  In place, the product with an inverted triangle
+      // is bound to the large tile (a workgroup may only overwrite what it alone has read): two tiles for 256 columns,
+      // 70 us on two compute units.  So the solved rows go to scratch, the update reads them there, and they are
+      // copied over A12 behind the event the panel stream waits for.
       T* A12 = A + k + (k + bs) * ld;
+      T* tmp = (all_inverted && solve_out_of_place_enabled()) ? w.solve_tmp : nullptr;
       LU_TRY(swap_rows(A + (k + bs) * ld, nb, upd));
-      LU_TRY(solve(A12, nb, upd));
-      LU_TRY(gemm_minus<T>(trows, nb, bs, A21, A12, A12 + bs, ld, upd));
+      LU_TRY(solve(A12, nb, upd, tmp));
+      LU_TRY(gemm_minus3<T>(trows, nb, bs, A21, ld, tmp ? tmp : A12, tmp ? bs : ld, A12 + bs, ld, upd));
+      LU_TRY(hipEventRecord(st.ready, upd));
+      if (tmp) LU_TRY(hipMemcpy2DAsync(A12, (size_t)ld * sizeof(T), tmp, (size_t)bs * sizeof(T), (size_t)bs * sizeof(T), (size_t)nb,
+                                       hipMemcpyDeviceToDevice, upd));
+    } else {
+      LU_TRY(hipEventRecord(st.ready, upd));
     }
-    LU_TRY(hipEventRecord(st.ready, upd));
     if (dealt_anew) {
       LU_TRY(hipEventRecord(st.resplit, upd));
       LU_TRY(hipStreamWaitEvent(upd2, st.resplit, 0));
@@ -2225,7 +2249,8 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   constexpr int kSets = 2 * kMaxSub + 1;
   const size_t off_linv = off_plan + kSets * round64(sizeof(SwapPlan));
   const size_t off_linvT = off_linv + kSets * round64((size_t)kPlanSpan * kPlanSpan * sizeof(T));
-  const size_t off_partials = off_linvT + kSets * round64((size_t)kPlanSpan * kPlanSpan * sizeof(T));
+  const size_t off_solve = off_linvT + kSets * round64((size_t)kPlanSpan * kPlanSpan * sizeof(T));
+  const size_t off_partials = off_solve + round64((size_t)kMaxSub * kPlanSpan * kMaxSub * kPlanSpan * sizeof(T));
   const size_t need = off_partials + round64(nparts * sizeof(Candidate<T>));
   if (!sc.buf_done) LU_TRY(hipEventCreateWithFlags(&sc.buf_done, hipEventDisableTiming));
   if (sc.buf_busy) {
@@ -2289,6 +2314,7 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   }
   static_assert(128 + kSets * 8 <= 208 && 208 + kRankCounters * 4 <= 256 && (kPlanSpan + kRankCols - 1) / kRankCols <= kRankCounters,
                 "the counters of lu_rowops_rank_update must fit the header and cover a panel of the look-ahead");
+  w.solve_tmp = reinterpret_cast<T*>(p + off_solve);
   w.partials = reinterpret_cast<Candidate<T>*>(p + off_partials);
   w.slots = reinterpret_cast<BaseSlot<T>*>(p + off_slots);
   LU_TRY(hipMemsetAsync(p, 0, 256, s));  // error flag of the fused base case, inverse flags and maxima
