@@ -341,6 +341,212 @@ template <typename T, int BATCH = 8> __device__ __forceinline__ void inverse_row
   note_inverse_max(job.gmax, mx);
 }
 
+// Columns of C a workgroup owns and how many of them a thread loads together.  32 / 16 against
+// 64 / 8: LU 8192^2 58.2 -> 55.9 ms (the kernel waits on its loads of C; more of them in flight and
+// twice the workgroups).  32 / 32 changes the float result in the last place (the compiler
+// reassociates something) and with it a pivot of the parity test: not used.
+#ifndef EIGAMD_LU_RANK_GROUP
+#define EIGAMD_LU_RANK_GROUP 16
+#endif
+#ifndef EIGAMD_LU_RANK_COLS
+#define EIGAMD_LU_RANK_COLS 32
+#endif
+constexpr int kRankCols = EIGAMD_LU_RANK_COLS;
+constexpr int kRankCounters = 8;   // arrival counters of lu_rowops_rank_update: bytes [208, 240) of the scratch header
+// lu_rowops and lu_rank_update of one 16-column block in ONE launch (a launch of the panel's chain costs 10 us and
+// more whatever it does; at 8192 rows the two were 14 + 13 us of a block's 95).  What the row operations change are
+// the block's "special" rows -- its jb top rows and the rows its transpositions name -- in the columns right of the
+// block; what the rank update needs of them is U12, the top rows after exchanges and forward substitution.  Every
+// workgroup of a column block reads the special rows of its 32 columns as they are, works out U12 and the exchanged
+// rows in LDS (redundantly: 32 rows x 32 columns), and updates its own 256 rows, skipping special ones.  Nobody
+// writes a special row while anybody may still read it: a workgroup counts itself in once its reads have landed in
+// LDS, and the workgroup that completes the count of its column block writes that block's special rows at the end --
+// U12 into the top rows, and "old top row - L(p, :) U12" into every named row p -- and puts the counter back to
+// zero.  No workgroup waits for another.  The columns left of the block inside the panel only exchange rows: extra
+// workgroups at the end of the grid, one thread per column.  Same operations per element, in the same order, as
+// lu_rowops followed by lu_rank_update.  Row and column arguments are absolute (`base` is the matrix).
+// (As a device function, so that the part of a block's update that nothing waits for -- the columns beyond the next
+// block's -- can run as extra workgroups of the next block's base-case launch, beside its sixteen exchanges.)
+template <typename T> struct RowopsArgs {
+  T* base = nullptr;
+  int64_t ld = 0;
+  const int* transp = nullptr;
+  int k0 = 0, jb = 0, cL = 0, cR = 0, nright = 0, cLeft0 = 0, nleft = 0, trows = 0, nrb = 0, ncb = 0;
+  int* counters = nullptr;
+  __host__ __device__ int workgroups() const { return nrb * ncb + (nleft + 255) / 256; }
+};
+template <typename T> struct RowopsShared {
+  T rows[2 * kMaxBase][kRankCols + 1];  // [0, 16): the top rows, then U12; [16, 32): the rows named by the transpositions
+  T l[kMaxBase * kMaxBase];
+  int p[kMaxBase];
+  int slot[kMaxBase];   // where row p[i] lives in rows
+  int last;
+};
+template <typename T, int GROUP = EIGAMD_LU_RANK_GROUP>
+__device__ __forceinline__ void rowops_rank_update_block(const RowopsArgs<T> args, const int b, RowopsShared<T>& sh) {
+  T* __restrict__ base = args.base;
+  const int64_t ld = args.ld;
+  const int* __restrict__ transp = args.transp;
+  const int k0 = args.k0, jb = args.jb, cL = args.cL, cR = args.cR, nright = args.nright, cLeft0 = args.cLeft0, nleft = args.nleft;
+  const int trows = args.trows, nrb = args.nrb, ncb = args.ncb;
+  int* __restrict__ counters = args.counters;
+  auto& s_rows = sh.rows;
+  auto& s_l = sh.l;
+  auto& s_p = sh.p;
+  auto& s_slot = sh.slot;
+  int& s_last = sh.last;
+  const int t = threadIdx.x;
+  if (t < kMaxBase) s_p[t] = t < jb ? transp[k0 + t] : -1;
+  for (int i = t; i < jb * jb; i += 256) s_l[(i % jb) + (i / jb) * kMaxBase] = base[(k0 + i % jb) + (int64_t)(cL + i / jb) * ld];
+  __syncthreads();
+  if (b >= nrb * ncb) {  // the columns to the left: exchanges only
+    const int c = (b - nrb * ncb) * 256 + t;
+    if (c < nleft) {
+      T* col = base + (int64_t)(cLeft0 + c) * ld;
+      for (int i = 0; i < jb; ++i) {
+        const int p = s_p[i];
+        if (p != k0 + i) {
+          const T v = col[k0 + i];
+          col[k0 + i] = col[p];
+          col[p] = v;
+        }
+      }
+    }
+    return;
+  }
+  const int rb = b % nrb, cb = b / nrb;
+  const int c0 = cb * kRankCols;
+  const int nc = min(kRankCols, nright - c0);
+  if (t < kMaxBase) {
+    int slot = -1;
+    if (t < jb) {
+      const int p = s_p[t];
+      if (p < k0 + jb) {
+        slot = p - k0;            // one of the top rows
+      } else {
+        slot = kMaxBase + t;      // a row below them: the slot of the first transposition that names it
+        for (int j = t - 1; j >= 0; --j)
+          if (s_p[j] == p) slot = kMaxBase + j;
+      }
+    }
+    s_slot[t] = slot;
+  }
+  __syncthreads();
+  T* colsR = base + (int64_t)(cR + c0) * ld;
+  for (int idx = t; idx < 2 * kMaxBase * kRankCols; idx += 256) {
+    const int half = idx / (kMaxBase * kRankCols), e = idx % (kMaxBase * kRankCols);
+    const int i = e % kMaxBase, j = e / kMaxBase;   // consecutive threads: consecutive top rows of one column
+    T v = (T)0;
+    if (i < jb && j < nc) {
+      if (half == 0) v = colsR[(k0 + i) + (int64_t)j * ld];
+      else if (s_slot[i] == kMaxBase + i) v = colsR[s_p[i] + (int64_t)j * ld];
+    }
+    s_rows[half * kMaxBase + i][j] = v;
+  }
+  __syncthreads();
+  // every special row this workgroup reads is in LDS now
+  if (t == 0) {
+    const int arrived = __hip_atomic_fetch_add(counters + cb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = arrived == nrb - 1;
+    if (last) __hip_atomic_store(counters + cb, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = last;
+  }
+  if (t < kRankCols) {  // one thread per column: the exchanges in order, then the forward substitution (as lu_rowops)
+    for (int i = 0; i < jb; ++i) {
+      if (s_p[i] != k0 + i) {
+        const int sl = s_slot[i];
+        const T v = s_rows[i][t];
+        s_rows[i][t] = s_rows[sl][t];
+        s_rows[sl][t] = v;
+      }
+    }
+    T x[kMaxBase];
+#pragma unroll
+    for (int i = 0; i < kMaxBase; ++i) x[i] = i < jb ? s_rows[i][t] : (T)0;
+#pragma unroll
+    for (int i = 0; i < kMaxBase; ++i) {
+      if (i < jb) {
+#pragma unroll
+        for (int rr = i + 1; rr < kMaxBase; ++rr)
+          if (rr < jb) x[rr] -= s_l[rr + i * kMaxBase] * x[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kMaxBase; ++i)
+      if (i < jb) s_rows[i][t] = x[i];
+  }
+  __syncthreads();
+  const int lr = rb * 256 + t;        // row of the trailing part
+  const int r = k0 + jb + lr;         // the same, absolute
+  bool plain = lr < trows;
+  if (plain)
+    for (int i = 0; i < jb; ++i)
+      if (s_p[i] == r) plain = false;  // a special row: the workgroup that completes the count writes it
+  if (plain) {
+    T a[kMaxBase];
+#pragma unroll
+    for (int k = 0; k < kMaxBase; ++k) a[k] = k < jb ? base[r + (int64_t)(cL + k) * ld] : (T)0;
+    T* Cr = colsR + r;
+    int j0 = 0;
+    constexpr int kGroup = GROUP;   // (8 where the block shares a base case's kernel and its register budget)
+    for (; j0 + kGroup <= nc; j0 += kGroup) {
+      T c[kGroup];
+#pragma unroll
+      for (int u = 0; u < kGroup; ++u) c[u] = Cr[(int64_t)(j0 + u) * ld];
+#pragma unroll
+      for (int u = 0; u < kGroup; ++u) {
+        T acc = (T)0;
+#pragma unroll
+        for (int k = 0; k < kMaxBase; ++k) acc += a[k] * s_rows[k][j0 + u];
+        c[u] -= acc;
+      }
+#pragma unroll
+      for (int u = 0; u < kGroup; ++u) Cr[(int64_t)(j0 + u) * ld] = c[u];
+    }
+    for (; j0 < nc; ++j0) {
+      T acc = (T)0;
+#pragma unroll
+      for (int k = 0; k < kMaxBase; ++k) acc += a[k] * s_rows[k][j0];
+      Cr[(int64_t)j0 * ld] -= acc;
+    }
+  }
+  if (s_last) {  // every workgroup of this column block has read the special rows: they may be written now
+    for (int e = t; e < kMaxBase * kRankCols; e += 256) {
+      const int i = e % kMaxBase, j = e / kMaxBase;
+      if (i < jb && j < nc) colsR[(k0 + i) + (int64_t)j * ld] = s_rows[i][j];
+    }
+    for (int e = t; e < kMaxBase * kRankCols; e += 256) {
+      const int i = e % kMaxBase, j = e / kMaxBase;
+      if (i < jb && j < nc && s_slot[i] == kMaxBase + i) {
+        const int p = s_p[i];
+        T acc = (T)0;
+#pragma unroll
+        for (int k = 0; k < kMaxBase; ++k) acc += (k < jb ? base[p + (int64_t)(cL + k) * ld] : (T)0) * s_rows[k][j];
+        colsR[p + (int64_t)j * ld] = s_rows[kMaxBase + i][j] - acc;
+      }
+    }
+  }
+}
+
+// What the launch of a block's base case carries besides the base case: rows of the enclosing panel's inverse and
+// the part of the block before's update that nothing waits for.
+template <typename T> struct Ride {
+  InvJob<T> inv;
+  RowopsArgs<T> far;
+  __host__ __device__ int inv_groups() const { return inv.i1 > inv.i0 ? kInvGroups : 0; }
+  __host__ __device__ int far_groups() const { return far.nright > 0 ? far.workgroups() : 0; }
+};
+// The extra workgroups of a base-case launch: `extra` = index behind the base case's own workgroups.
+template <typename T> __device__ __forceinline__ void run_ride(const Ride<T> ride, const int extra) {
+  if (extra < ride.inv_groups()) {
+    __shared__ InvShared<T> s_inv;
+    inverse_rows_job<T>(ride.inv, extra, s_inv);
+    return;
+  }
+  __shared__ RowopsShared<T> s_far;
+  rowops_rank_update_block<T, 8>(ride.far, extra - ride.inv_groups(), s_far);
+}
+
 // ---- the base case in one kernel ---------------------------------------------------
 //
 // The workgroups of the fused base case agree on each pivot through an exchange area in
@@ -441,18 +647,17 @@ template <typename T>
 __global__ void __launch_bounds__(kRowsPerBlock, 4)
     lu_base_fused(T* __restrict__ P, int64_t ld, int rows, int jbw, int size, int* __restrict__ transp,
                   int row_offset, int col_global, BaseSlot<T>* __restrict__ slots, BaseTop<T>* __restrict__ tops,
-                  unsigned gen0, int* __restrict__ error, int* __restrict__ first_zero, int* __restrict__ nswaps, InvJob<T> job) {
+                  unsigned gen0, int* __restrict__ error, int* __restrict__ first_zero, int* __restrict__ nswaps, Ride<T> ride) {
   __shared__ T s_u[kMaxBase];
   __shared__ T s_top[kMaxBase];
   __shared__ unsigned s_pub[kRowsPerBlock / 64][kMaxBase * Words<T>::N];  // per wavefront: the words of the row it is about to publish
   __shared__ int s_win_row, s_flags;   // the winner's row; 1: the pivot is exactly zero, 2: gave up waiting
   constexpr int NW = Words<T>::N;
-  // The last workgroups of the grid take no part in the factorisation: rows of the enclosing panel's inverse
-  // (InvJob), which fit into the time the others spend on their sixteen exchanges.
-  const int nparts = (int)gridDim.x - (job.i1 > job.i0 ? kInvGroups : 0);
+  // The last workgroups of the grid take no part in the factorisation: rows of the enclosing panel's inverse and
+  // the far part of the block before's update (Ride), in the time the others spend on their sixteen exchanges.
+  const int nparts = (int)gridDim.x - ride.inv_groups() - ride.far_groups();
   if ((int)blockIdx.x >= nparts) {
-    __shared__ InvShared<T> s_inv;
-    inverse_rows_job<T>(job, (int)blockIdx.x - nparts, s_inv);
+    run_ride<T>(ride, (int)blockIdx.x - nparts);
     return;
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -675,10 +880,9 @@ constexpr int kSingleThreads = 1024, kSingleRpt = 2, kSingleRows = kSingleThread
 template <typename T>
 __global__ void __launch_bounds__(kSingleThreads)
     lu_base_single(T* __restrict__ P, int64_t ld, int rows, int jbw, int size, int* __restrict__ transp, int row_offset,
-                   int col_global, int* __restrict__ first_zero, int* __restrict__ nswaps, InvJob<T> job) {
-  if (blockIdx.x > 0) {   // rows of the enclosing panel's inverse (InvJob): a job's workgroup has 256 threads
-    __shared__ InvShared<T> s_inv;
-    if (threadIdx.x < 256) inverse_rows_job<T>(job, (int)blockIdx.x - 1, s_inv);
+                   int col_global, int* __restrict__ first_zero, int* __restrict__ nswaps, Ride<T> ride) {
+  if (blockIdx.x > 0) {   // what rides along (Ride): those workgroups work with 256 threads
+    if (threadIdx.x < 256) run_ride<T>(ride, (int)blockIdx.x - 1);
     return;
   }
   __shared__ T s_u[kMaxBase];
@@ -850,18 +1054,6 @@ __global__ void lu_laswp(T* __restrict__ A, int64_t ld, int ncols, const int* __
 // panel after one base case (PartialPivLU.h:494 at the inner level).  Two flops per 16 bytes
 // of C: a streaming kernel -- thread = one row of A in registers, a 64-column slab of B in
 // LDS -- in ONE launch, where the GEMM kernel needs an interior launch and edge strips.
-// Columns of C a workgroup owns and how many of them a thread loads together.  32 / 16 against
-// 64 / 8: LU 8192^2 58.2 -> 55.9 ms (the kernel waits on its loads of C; more of them in flight and
-// twice the workgroups).  32 / 32 changes the float result in the last place (the compiler
-// reassociates something) and with it a pivot of the parity test: not used.
-#ifndef EIGAMD_LU_RANK_GROUP
-#define EIGAMD_LU_RANK_GROUP 16
-#endif
-#ifndef EIGAMD_LU_RANK_COLS
-#define EIGAMD_LU_RANK_COLS 32
-#endif
-constexpr int kRankCols = EIGAMD_LU_RANK_COLS;
-constexpr int kRankCounters = 8;   // arrival counters of lu_rowops_rank_update: bytes [208, 240) of the scratch header
 template <typename T>
 __global__ void __launch_bounds__(256) lu_rank_update(const T* __restrict__ A, const T* __restrict__ B, T* __restrict__ C,
                                                       int64_t ld, int rows, int cols, int jb) {
@@ -903,159 +1095,10 @@ __global__ void __launch_bounds__(256) lu_rank_update(const T* __restrict__ A, c
   }
 }
 
-// lu_rowops and lu_rank_update of one 16-column block in ONE launch (a launch of the panel's chain costs 10 us and
-// more whatever it does; at 8192 rows the two were 14 + 13 us of a block's 95).  What the row operations change are
-// the block's "special" rows -- its jb top rows and the rows its transpositions name -- in the columns right of the
-// block; what the rank update needs of them is U12, the top rows after exchanges and forward substitution.  Every
-// workgroup of a column block reads the special rows of its 32 columns as they are, works out U12 and the exchanged
-// rows in LDS (redundantly: 32 rows x 32 columns), and updates its own 256 rows, skipping special ones.  Nobody
-// writes a special row while anybody may still read it: a workgroup counts itself in once its reads have landed in
-// LDS, and the workgroup that completes the count of its column block writes that block's special rows at the end --
-// U12 into the top rows, and "old top row - L(p, :) U12" into every named row p -- and puts the counter back to
-// zero.  No workgroup waits for another.  The columns left of the block inside the panel only exchange rows: extra
-// workgroups at the end of the grid, one thread per column.  Same operations per element, in the same order, as
-// lu_rowops followed by lu_rank_update.  Row and column arguments are absolute (`base` is the matrix).
 template <typename T>
-__global__ void __launch_bounds__(256) lu_rowops_rank_update(T* __restrict__ base, int64_t ld, const int* __restrict__ transp,
-                                                            int k0, int jb, int cL, int cR, int nright, int cLeft0, int nleft,
-                                                            int trows, int nrb, int ncb, int* __restrict__ counters) {
-  __shared__ T s_rows[2 * kMaxBase][kRankCols + 1];  // [0, 16): the top rows, then U12; [16, 32): the rows named by the transpositions
-  __shared__ T s_l[kMaxBase * kMaxBase];
-  __shared__ int s_p[kMaxBase];
-  __shared__ int s_slot[kMaxBase];   // where row s_p[i] lives in s_rows
-  __shared__ int s_last;
-  const int t = threadIdx.x;
-  if (t < kMaxBase) s_p[t] = t < jb ? transp[k0 + t] : -1;
-  for (int i = t; i < jb * jb; i += 256) s_l[(i % jb) + (i / jb) * kMaxBase] = base[(k0 + i % jb) + (int64_t)(cL + i / jb) * ld];
-  __syncthreads();
-  const int b = blockIdx.x;
-  if (b >= nrb * ncb) {  // the columns to the left: exchanges only
-    const int c = (b - nrb * ncb) * 256 + t;
-    if (c < nleft) {
-      T* col = base + (int64_t)(cLeft0 + c) * ld;
-      for (int i = 0; i < jb; ++i) {
-        const int p = s_p[i];
-        if (p != k0 + i) {
-          const T v = col[k0 + i];
-          col[k0 + i] = col[p];
-          col[p] = v;
-        }
-      }
-    }
-    return;
-  }
-  const int rb = b % nrb, cb = b / nrb;
-  const int c0 = cb * kRankCols;
-  const int nc = min(kRankCols, nright - c0);
-  if (t < kMaxBase) {
-    int slot = -1;
-    if (t < jb) {
-      const int p = s_p[t];
-      if (p < k0 + jb) {
-        slot = p - k0;            // one of the top rows
-      } else {
-        slot = kMaxBase + t;      // a row below them: the slot of the first transposition that names it
-        for (int j = t - 1; j >= 0; --j)
-          if (s_p[j] == p) slot = kMaxBase + j;
-      }
-    }
-    s_slot[t] = slot;
-  }
-  __syncthreads();
-  T* colsR = base + (int64_t)(cR + c0) * ld;
-  for (int idx = t; idx < 2 * kMaxBase * kRankCols; idx += 256) {
-    const int half = idx / (kMaxBase * kRankCols), e = idx % (kMaxBase * kRankCols);
-    const int i = e % kMaxBase, j = e / kMaxBase;   // consecutive threads: consecutive top rows of one column
-    T v = (T)0;
-    if (i < jb && j < nc) {
-      if (half == 0) v = colsR[(k0 + i) + (int64_t)j * ld];
-      else if (s_slot[i] == kMaxBase + i) v = colsR[s_p[i] + (int64_t)j * ld];
-    }
-    s_rows[half * kMaxBase + i][j] = v;
-  }
-  __syncthreads();
-  // every special row this workgroup reads is in LDS now
-  if (t == 0) {
-    const int arrived = __hip_atomic_fetch_add(counters + cb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = arrived == nrb - 1;
-    if (last) __hip_atomic_store(counters + cb, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = last;
-  }
-  if (t < kRankCols) {  // one thread per column: the exchanges in order, then the forward substitution (as lu_rowops)
-    for (int i = 0; i < jb; ++i) {
-      if (s_p[i] != k0 + i) {
-        const int sl = s_slot[i];
-        const T v = s_rows[i][t];
-        s_rows[i][t] = s_rows[sl][t];
-        s_rows[sl][t] = v;
-      }
-    }
-    T x[kMaxBase];
-#pragma unroll
-    for (int i = 0; i < kMaxBase; ++i) x[i] = i < jb ? s_rows[i][t] : (T)0;
-#pragma unroll
-    for (int i = 0; i < kMaxBase; ++i) {
-      if (i < jb) {
-#pragma unroll
-        for (int rr = i + 1; rr < kMaxBase; ++rr)
-          if (rr < jb) x[rr] -= s_l[rr + i * kMaxBase] * x[i];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < kMaxBase; ++i)
-      if (i < jb) s_rows[i][t] = x[i];
-  }
-  __syncthreads();
-  const int lr = rb * 256 + t;        // row of the trailing part
-  const int r = k0 + jb + lr;         // the same, absolute
-  bool plain = lr < trows;
-  if (plain)
-    for (int i = 0; i < jb; ++i)
-      if (s_p[i] == r) plain = false;  // a special row: the workgroup that completes the count writes it
-  if (plain) {
-    T a[kMaxBase];
-#pragma unroll
-    for (int k = 0; k < kMaxBase; ++k) a[k] = k < jb ? base[r + (int64_t)(cL + k) * ld] : (T)0;
-    T* Cr = colsR + r;
-    int j0 = 0;
-    constexpr int kGroup = EIGAMD_LU_RANK_GROUP;
-    for (; j0 + kGroup <= nc; j0 += kGroup) {
-      T c[kGroup];
-#pragma unroll
-      for (int u = 0; u < kGroup; ++u) c[u] = Cr[(int64_t)(j0 + u) * ld];
-#pragma unroll
-      for (int u = 0; u < kGroup; ++u) {
-        T acc = (T)0;
-#pragma unroll
-        for (int k = 0; k < kMaxBase; ++k) acc += a[k] * s_rows[k][j0 + u];
-        c[u] -= acc;
-      }
-#pragma unroll
-      for (int u = 0; u < kGroup; ++u) Cr[(int64_t)(j0 + u) * ld] = c[u];
-    }
-    for (; j0 < nc; ++j0) {
-      T acc = (T)0;
-#pragma unroll
-      for (int k = 0; k < kMaxBase; ++k) acc += a[k] * s_rows[k][j0];
-      Cr[(int64_t)j0 * ld] -= acc;
-    }
-  }
-  if (s_last) {  // every workgroup of this column block has read the special rows: they may be written now
-    for (int e = t; e < kMaxBase * kRankCols; e += 256) {
-      const int i = e % kMaxBase, j = e / kMaxBase;
-      if (i < jb && j < nc) colsR[(k0 + i) + (int64_t)j * ld] = s_rows[i][j];
-    }
-    for (int e = t; e < kMaxBase * kRankCols; e += 256) {
-      const int i = e % kMaxBase, j = e / kMaxBase;
-      if (i < jb && j < nc && s_slot[i] == kMaxBase + i) {
-        const int p = s_p[i];
-        T acc = (T)0;
-#pragma unroll
-        for (int k = 0; k < kMaxBase; ++k) acc += (k < jb ? base[p + (int64_t)(cL + k) * ld] : (T)0) * s_rows[k][j];
-        colsR[p + (int64_t)j * ld] = s_rows[kMaxBase + i][j] - acc;
-      }
-    }
-  }
+__global__ void __launch_bounds__(256) lu_rowops_rank_update(RowopsArgs<T> args) {
+  __shared__ RowopsShared<T> sh;
+  rowops_rank_update_block<T>(args, (int)blockIdx.x, sh);
 }
 
 // ---- many transpositions at once ----------------------------------------------------
@@ -1627,29 +1670,31 @@ template <typename T> struct Workspace {
   double inverse_limit;
   int* rank_count;      // per column block of lu_rowops_rank_update (zero between launches), or null: two launches
   int64_t rank_fused_max;  // ... used for panels of at most this many rows below the block (taller: two launches)
+  int64_t far_rides_max;   // the far part of a block's update rides in the next base-case launch up to this many rows below the block
 };
 constexpr int kOwnScratch = 2 * kMaxSub;
 
 // unblocked_lu (PartialPivLU.h:357-412) on the rows x jbw sub-panel at P.
 template <typename T>
 hipError_t unblocked(T* P, int64_t ld, int64_t rows, int jbw, int* transp, int row_offset, int col_offset,
-                     const Workspace<T>& w, hipStream_t s, const InvJob<T>& ride = InvJob<T>()) {
+                     const Workspace<T>& w, hipStream_t s, const Ride<T>& ride = Ride<T>()) {
   const int size = (int)std::min<int64_t>(rows, jbw);
   int nparts = (int)((rows + kRowsPerBlock - 1) / kRowsPerBlock);
-  const int njob = ride.i1 > ride.i0 ? kInvGroups : 0;   // extra workgroups at the end of the grid: rows of the panel's inverse
+  const int njob = ride.inv_groups() + ride.far_groups();   // extra workgroups at the end of the grid (they wait for nobody)
   if (rows <= kSingleRows && w.rule.single) {
     hipLaunchKernelGGL(lu_base_single<T>, dim3(1 + njob), dim3(kSingleThreads), 0, s, P, ld, (int)rows, jbw, size, transp,
                        row_offset, col_offset, w.first_zero, w.nswaps, ride);
     return hipGetLastError();
   }
-  if (nparts + njob <= w.fused_capacity && w.rule.fused) {
+  if (nparts <= w.fused_capacity && w.rule.fused) {   // (the base case's own workgroups are dispatched first)
     const unsigned gen0 = *w.generation;
     *w.generation += (unsigned)size;
     hipLaunchKernelGGL(lu_base_fused<T>, dim3(nparts + njob), dim3(kRowsPerBlock), 0, s, P, ld, (int)rows, jbw, size, transp,
                        row_offset, col_offset, w.slots, w.tops, gen0, w.error, w.first_zero, w.nswaps, ride);
     return hipGetLastError();
   }
-  if (njob) hipLaunchKernelGGL(lu_inverse_rows<T>, dim3(kInvGroups), dim3(256), 0, s, ride);
+  if (ride.far_groups()) hipLaunchKernelGGL(lu_rowops_rank_update<T>, dim3((unsigned)ride.far_groups()), dim3(256), 0, s, ride.far);
+  if (ride.inv_groups()) hipLaunchKernelGGL(lu_inverse_rows<T>, dim3(kInvGroups), dim3(256), 0, s, ride.inv);
   hipLaunchKernelGGL(lu_colmax<T>, dim3(nparts), dim3(kRowsPerBlock), 0, s, P, ld, 0, (int)rows, 0, w.partials);
   for (int jj = 0; jj < size; ++jj) {
     hipLaunchKernelGGL(lu_pivot<T>, dim3(1), dim3(64), 0, s, P, ld, jbw, jj, w.partials, nparts, transp + jj, row_offset,
@@ -1735,6 +1780,13 @@ hipError_t make_inverse(const T* L, int64_t ldl, int64_t bs, T* X, int* flag, un
   hipLaunchKernelGGL(lu_inverse_finish<T>, dim3(1), dim3(256), 0, s, X, (int)bs, limit, gmax, flag);
   return hipGetLastError();
 }
+inline bool far_rides_enabled() {   // EIGAMD_LU_FAR_RIDES=0: a block's whole update in the launch between two base cases
+  static const bool on = [] {
+    const char* e = std::getenv("EIGAMD_LU_FAR_RIDES");
+    return !(e && std::atoi(e) == 0);
+  }();
+  return on;
+}
 inline bool solve_out_of_place_enabled() {   // EIGAMD_LU_SOLVE_TMP=0: the next step's columns are solved in place
   static const bool on = [] {
     const char* e = std::getenv("EIGAMD_LU_SOLVE_TMP");
@@ -1772,7 +1824,7 @@ hipError_t apply_inverse(const T* X, const int* flag, const T* L, int64_t ldl, i
 template <typename T>
 hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows, int64_t cols, int* transp,
                    int64_t max_block, const Workspace<T>& w, hipStream_t s, int64_t force_block = 0,
-                   const InverseTarget<T>* inv = nullptr, InvJob<T> ride = InvJob<T>()) {
+                   const InverseTarget<T>* inv = nullptr, const Ride<T>& ride = Ride<T>()) {
   T* A = base + row0 + col0 * ld;
   const int64_t size = std::min(rows, cols);
   if (size <= kMaxBase) {
@@ -1802,6 +1854,8 @@ hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows
     return job;
   };
   const InverseTarget<T> own = {w.linv[kOwnScratch], w.linv_flag[kOwnScratch], w.linv_max[kOwnScratch], w.linvT[kOwnScratch]};
+  // (panel level) the far part of the block before's update: it rides in the launch of this block's base case
+  RowopsArgs<T> pending_far;
   for (int64_t k = 0; k < size; k += block) {
     const int64_t bs = std::min(size - k, block);
     const int64_t trows = rows - k - bs, tsize = size - k - bs;
@@ -1809,8 +1863,11 @@ hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows
     const bool inverted_on_the_way = block > kMaxBase && trows > 0 && inverse_applies<T>(bs) && incremental_inverse_enabled();
     // the panel [A11; A21], recursively with blocks of 16 (:472-473); at panel level the launch of this block's base
     // case carries the rows of the inverse that belong to the blocks before it (their part of L no longer moves)
-    LU_TRY(blocked<T>(base, ld, row0 + k, col0 + k, trows + bs, bs, transp, 16, w, s, 0, inverted_on_the_way ? &target : nullptr,
-                      inverse_job(k)));
+    Ride<T> carried;
+    carried.inv = inverse_job(k);
+    carried.far = pending_far;
+    pending_far = RowopsArgs<T>();
+    LU_TRY(blocked<T>(base, ld, row0 + k, col0 + k, trows + bs, bs, transp, 16, w, s, 0, inverted_on_the_way ? &target : nullptr, carried));
     if (bs <= kMaxBase) {
       // Narrow blocks (inside a panel): the transpositions on both sides (A_0 :479-483, A_2
       // :488-489) and the triangular solve (:492) in one launch, then the rank-bs update (:494).
@@ -1820,12 +1877,24 @@ hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows
       // that hands a wide matrix to blocked() with blocks of 16 (max_block_size <= 16) may have more, and takes
       // the two launches.
       const int ncb = (int)((tsize + kRankCols - 1) / kRankCols);
-      if (w.rank_count && trows > 0 && trows <= w.rank_fused_max && tsize > 0 && ncb <= kRankCounters) {
-        const int nrb = (int)((trows + 255) / 256);
-        const int nleft_wg = (int)((k + 255) / 256);
-        hipLaunchKernelGGL(lu_rowops_rank_update<T>, dim3((unsigned)(nrb * ncb + nleft_wg)), dim3(256), 0, s,
-                           base, ld, transp, (int)(row0 + k), (int)bs, (int)(col0 + k), (int)(col0 + k + bs), (int)tsize, (int)col0,
-                           (int)k, (int)trows, nrb, ncb, w.rank_count);
+      const bool far_rides = far_rides_enabled() && ncb <= kRankCounters && trows <= w.far_rides_max;
+      if (w.rank_count && trows > 0 && (trows <= w.rank_fused_max || far_rides) && tsize > 0 && ncb <= kRankCounters) {
+        RowopsArgs<T> ra;
+        ra.base = base; ra.ld = ld; ra.transp = transp;
+        ra.k0 = (int)(row0 + k); ra.jb = (int)bs; ra.cL = (int)(col0 + k); ra.cR = (int)(col0 + k + bs); ra.nright = (int)tsize;
+        ra.cLeft0 = (int)col0; ra.nleft = (int)k; ra.trows = (int)trows;
+        ra.nrb = (int)((trows + 255) / 256); ra.ncb = ncb; ra.counters = w.rank_count;
+        if (far_rides) {
+          // Only the next block's columns stand between this block and the next base case; the columns beyond them
+          // are updated by extra workgroups of that base case's launch (same operations per element, same order:
+          // that launch comes before the next block's own row operations).
+          const int near = (int)std::min<int64_t>(block, tsize);
+          pending_far = ra;
+          pending_far.cR = ra.cR + near; pending_far.nright = ra.nright - near; pending_far.nleft = 0;
+          pending_far.ncb = (pending_far.nright + kRankCols - 1) / kRankCols;
+          ra.nright = near; ra.ncb = 1;
+        }
+        hipLaunchKernelGGL(lu_rowops_rank_update<T>, dim3((unsigned)ra.workgroups()), dim3(256), 0, s, ra);
         LU_TRY(hipGetLastError());
         continue;
       }
@@ -1868,6 +1937,10 @@ hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows
       }
       LU_TRY(gemm_minus<T>(trows, tsize, bs, A21, A12, A22, ld, s));  // (:494) the GEMM hot path
     }
+  }
+  if (pending_far.nright > 0) {   // (a far part that found no base case to ride in)
+    hipLaunchKernelGGL(lu_rowops_rank_update<T>, dim3((unsigned)pending_far.workgroups()), dim3(256), 0, s, pending_far);
+    LU_TRY(hipGetLastError());
   }
   return hipSuccess;
 }
@@ -2311,6 +2384,8 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
     w.rank_count = fuse ? reinterpret_cast<int*>(p) + 52 : nullptr;   // bytes [208, 240) of the header, cleared below
     w.rank_fused_max = 4608;
     if (const char* e = getenv("EIGAMD_LU_FUSED_ROWOPS_MAX")) w.rank_fused_max = atoll(e);
+    w.far_rides_max = 12288;   // (swept: 8192^2 44.3 ms from 8192 rows on, 16384^2 121.7 / 121.1 / 120.0 / 120.1 and 32768^2 497.5 / 496.1 / 494.7 / 497.9 ms for 4608 / 8192 / 12288 / 16384)
+    if (const char* e = getenv("EIGAMD_LU_FAR_RIDES_MAX")) w.far_rides_max = atoll(e);
   }
   static_assert(128 + kSets * 8 <= 208 && 208 + kRankCounters * 4 <= 256 && (kPlanSpan + kRankCols - 1) / kRankCols <= kRankCounters,
                 "the counters of lu_rowops_rank_update must fit the header and cover a panel of the look-ahead");
