@@ -244,6 +244,13 @@ __device__ __forceinline__ double abs_max2(double m, double v) {
 // columns to its left.  A few extra workgroups of the next block's base-case launch do it (that launch spends 50 us
 // and more on its sixteen exchanges, the rows take less); what remains behind the panel is the last 16 rows and the
 // look at max|X| (lu_inverse_rows, lu_inverse_tail: two short launches).
+constexpr int kPlanSpan = 256;
+constexpr int kMaxSub = 4;  // an outer step of the look-ahead spans at most kMaxSub * kPlanSpan columns
+struct SwapPlan {   // (see lu_swap_plan)
+  int count;
+  int dst[2 * kPlanSpan];
+  int src[2 * kPlanSpan];
+};
 template <typename T> struct InvJob {
   const T* L = nullptr;   // the bs x bs block (unit lower triangle), leading dimension ldl
   int64_t ldl = 0;
@@ -251,6 +258,10 @@ template <typename T> struct InvJob {
   T* XT = nullptr;        // the transpose of X (scratch of the job: what it reads back is contiguous along its lanes)
   unsigned long long* gmax = nullptr;
   int bs = 0, i0 = 0, i1 = 0;   // rows [i0, i1) are to be formed; rows [0, i0) are there
+  // (the launch behind the panel only) the panel's transpositions [k0, k1) as one permutation, by one more workgroup
+  SwapPlan* plan = nullptr;
+  const int* transp = nullptr;
+  int k0 = 0, k1 = 0;
 };
 // A job is dealt over kInvGroups workgroups of 256 threads, 64 columns of X each: lane = column, wavefront = four of
 // the sixteen rows of a row block.  With M = E - L(rows, above) X(above, :) the rows are X(rows, :) = inv(L(rows, rows)) M:
@@ -1108,15 +1119,8 @@ __global__ void __launch_bounds__(256) lu_rowops_rank_update(RowopsArgs<T> args)
 // of moves "row dst receives what row src held" (in no particular order);
 // lu_apply_plan then moves whole row segments with independent loads, instead of one
 // dependent load-store pair per transposition and column.
-constexpr int kPlanSpan = 256;
-constexpr int kMaxSub = 4;  // an outer step of the look-ahead spans at most kMaxSub * kPlanSpan columns
-struct SwapPlan {
-  int count;
-  int dst[2 * kPlanSpan];
-  int src[2 * kPlanSpan];
-};
 
-__global__ void __launch_bounds__(kPlanSpan) lu_swap_plan(const int* __restrict__ transp, int k0, int k1, SwapPlan* __restrict__ plan) {
+__device__ __forceinline__ void swap_plan_block(const int* __restrict__ transp, int k0, int k1, SwapPlan* __restrict__ plan) {
   // Every row that takes part is followed through the run by a thread of its own: the rows
   // [k0, k1) and each row outside them that some transposition names (once, by the first
   // transposition that names it).  The walks are independent of each other, read the run from
@@ -1154,6 +1158,9 @@ __global__ void __launch_bounds__(kPlanSpan) lu_swap_plan(const int* __restrict_
   }
   __syncthreads();
   if (t == 0) plan->count = s_count;
+}
+__global__ void __launch_bounds__(kPlanSpan) lu_swap_plan(const int* __restrict__ transp, int k0, int k1, SwapPlan* __restrict__ plan) {
+  swap_plan_block(transp, k0, k1, plan);
 }
 
 // Applies a plan to `ncols` columns starting at A; a workgroup owns kPlanCols columns.  A thread takes one move
@@ -1498,6 +1505,10 @@ __global__ void __launch_bounds__(256) lu_inverse_finish(T* __restrict__ X, int 
 // at max|X| (lu_inverse_tail, as lu_inverse_finish).
 template <typename T>
 __global__ void __launch_bounds__(256) lu_inverse_rows(InvJob<T> job) {
+  if ((int)blockIdx.x >= kInvGroups) {   // one more workgroup: the panel's transpositions as one permutation
+    swap_plan_block(job.transp, job.k0, job.k1, job.plan);
+    return;
+  }
   __shared__ InvShared<T> s_inv;
   inverse_rows_job<T, 32>(job, (int)blockIdx.x, s_inv);
 }
@@ -1641,6 +1652,7 @@ template <typename T> struct InverseTarget {
   int* flag = nullptr;
   unsigned long long* gmax = nullptr;
   T* XT = nullptr;   // scratch for the transpose (InvJob)
+  SwapPlan* plan = nullptr;   // when set: the launch behind the panel also turns the panel's transpositions into this plan
 };
 
 template <typename T> struct Workspace {
@@ -1913,7 +1925,9 @@ hipError_t blocked(T* base, int64_t ld, int64_t row0, int64_t col0, int64_t rows
       }
       if (build_inverse && k + bs >= size) {   // the panel's last block: what is left of the inverse, and the look at max|X|
         InvJob<T> job = inverse_job(size);
-        if (job.i1 > job.i0) hipLaunchKernelGGL(lu_inverse_rows<T>, dim3(kInvGroups), dim3(256), 0, s, job);
+        if (inv[0].plan) { job.plan = inv[0].plan; job.transp = transp; job.k0 = (int)row0; job.k1 = (int)(row0 + size); }
+        if (job.i1 > job.i0) hipLaunchKernelGGL(lu_inverse_rows<T>, dim3(kInvGroups + (job.plan ? 1 : 0)), dim3(256), 0, s, job);
+        else if (job.plan) LU_TRY(make_plan(transp, job.k0, job.k1, job.plan, s));
         job.X = inv[0].X; job.gmax = inv[0].gmax; job.bs = (int)size;
         hipLaunchKernelGGL(lu_inverse_tail<T>, dim3(1), dim3(256), 0, s, job, w.inverse_limit, inv[0].flag);
         LU_TRY(hipGetLastError());
@@ -2062,7 +2076,7 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
     // The inverted triangles of the step's pieces are built while the pieces are factorised (InvJob), straight into
     // this step's scratch; EIGAMD_LU_INVERSE_ON_THE_WAY=0: by the chain of launches behind the panel, as before.
     InverseTarget<T> targets[kMaxSub];
-    for (int i = 0; i < nsub; ++i) targets[i] = {linv[i], linv_flag[i], w.linv_max[par * kMaxSub + i], w.linvT[par * kMaxSub + i]};
+    for (int i = 0; i < nsub; ++i) targets[i] = {linv[i], linv_flag[i], w.linv_max[par * kMaxSub + i], w.linvT[par * kMaxSub + i], plan[i]};
     const bool on_the_way = incremental_inverse_enabled() && trows > 0 && planned;
     if (bs > rule_block) {
       LU_TRY(blocked<T>(A, ld, k, k, trows + bs, bs, transp, 16, w, pan, rule_block, on_the_way && rule_block == kPlanSpan ? targets : nullptr));
@@ -2072,7 +2086,7 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
       LU_TRY(blocked<T>(A, ld, k, k, trows + bs, bs, transp, 16, w, pan, 0, direct ? targets : nullptr));
     }
     const bool pieces_inverted = on_the_way && (bs > rule_block ? rule_block == kPlanSpan : true);
-    if (planned)
+    if (planned && !pieces_inverted)   // (otherwise the plans came with the inverses)
       for (int i = 0; i < nsub; ++i)
         LU_TRY(make_plan(transp, (int)(k + sub_begin(i)), (int)(k + sub_begin(i) + sub_size(i)), plan[i], pan));
     // The update streams start on the row exchanges as soon as the plans are there; the inverted triangles,
