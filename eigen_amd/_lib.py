@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libeigen_amd_blas.so")
 
 F32, F64, C32, C64 = 0, 1, 2, 3
 OP_N, OP_T, OP_C, OP_CONJ = 0, 1, 2, 3
-OK, ERR_ARG, ERR_DEVICE, ERR_NO_GPU = 0, -1, -2, -3
+OK, ERR_ARG, ERR_DEVICE, ERR_NO_GPU, ERR_NOT_RESIDENT = 0, -1, -2, -3, -4
 
 
 class LibraryMissing(RuntimeError):
@@ -64,6 +64,8 @@ lib.eigamd_blocked_lu_host_rowmajor.restype = ctypes.c_int
 lib.eigamd_blocked_lu_host_rowmajor.argtypes = lib.eigamd_blocked_lu_host.argtypes
 lib.eigamd_getrf_dev.restype = ctypes.c_int
 lib.eigamd_getrf_dev.argtypes = [ctypes.c_int, _i64, _i64, _vp, _i64, _vp, _i64, _i32ptr, _i32ptr, _vp]
+lib.eigamd_getrf_dev_shared.restype = ctypes.c_int
+lib.eigamd_getrf_dev_shared.argtypes = lib.eigamd_getrf_dev.argtypes
 lib.eigamd_getrf_dev_async.restype = ctypes.c_int
 lib.eigamd_getrf_dev_async.argtypes = [ctypes.c_int, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp]
 lib.eigamd_laswp_dev.restype = ctypes.c_int

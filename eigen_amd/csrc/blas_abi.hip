@@ -1103,8 +1103,9 @@ int eigamd_fill_uniform_host(int dtype, void* x, int64_t rows, int64_t cols, int
   return EIGAMD_OK;
 }
 
-int eigamd_getrf_dev(int dtype, int64_t m, int64_t n, void* d_a, int64_t lda, int* d_transp,
-                     int64_t max_block_size, int* first_zero_pivot, int* nb_transpositions, void* stream) {
+namespace {
+int getrf_dev_impl(int dtype, int64_t m, int64_t n, void* d_a, int64_t lda, int* d_transp, int64_t max_block_size,
+                   int* first_zero_pivot, int* nb_transpositions, void* stream, bool allow_fused) {
   if (dtype < 0 || dtype > 3) return fail(EIGAMD_ERR_ARG, "invalid dtype");
   if (m < 0 || n < 0 || lda < std::max<int64_t>(1, m) || m > 0x7fffffff || n > 0x7fffffff)
     return fail(EIGAMD_ERR_ARG, "invalid LU arguments");
@@ -1112,16 +1113,28 @@ int eigamd_getrf_dev(int dtype, int64_t m, int64_t n, void* d_a, int64_t lda, in
   if (m > 0 && n > 0) {
     int rc = ensure_device();
     if (rc != EIGAMD_OK) return rc;
-    const hipError_t e = getrf_device(dtype, m, n, d_a, lda, d_transp, max_block_size, &fz, &nb, static_cast<hipStream_t>(stream));
+    const hipError_t e =
+        getrf_device(dtype, m, n, d_a, lda, d_transp, max_block_size, &fz, &nb, static_cast<hipStream_t>(stream), allow_fused);
     if (e == kLuNotResident)
-      return fail(EIGAMD_ERR_DEVICE,
+      return fail(EIGAMD_ERR_NOT_RESIDENT,
                   "LU: the workgroups of a panel kernel were not resident together (device shared with other work); "
-                  "the matrix is partly overwritten: restore it and call again with EIGAMD_LU_FUSED=0");
+                  "the matrix is partly overwritten: restore it and call eigamd_getrf_dev_shared");
     if (e != hipSuccess) return hip_fail(e, "getrf_device");
   }
   if (first_zero_pivot) *first_zero_pivot = fz;
   if (nb_transpositions) *nb_transpositions = nb;
   return EIGAMD_OK;
+}
+}  // namespace
+
+int eigamd_getrf_dev(int dtype, int64_t m, int64_t n, void* d_a, int64_t lda, int* d_transp,
+                     int64_t max_block_size, int* first_zero_pivot, int* nb_transpositions, void* stream) {
+  return getrf_dev_impl(dtype, m, n, d_a, lda, d_transp, max_block_size, first_zero_pivot, nb_transpositions, stream, true);
+}
+
+int eigamd_getrf_dev_shared(int dtype, int64_t m, int64_t n, void* d_a, int64_t lda, int* d_transp,
+                            int64_t max_block_size, int* first_zero_pivot, int* nb_transpositions, void* stream) {
+  return getrf_dev_impl(dtype, m, n, d_a, lda, d_transp, max_block_size, first_zero_pivot, nb_transpositions, stream, false);
 }
 
 int eigamd_getrf_dev_async(int dtype, int64_t m, int64_t n, void* d_a, int64_t lda, int* d_transp, int64_t max_block_size,

@@ -55,18 +55,27 @@ def getrf(a):
     return ipiv[:min(m, n)], info.value
 
 
-def getrf_dev(a, stream=None, max_block_size=256, transp=None):
+class NotResident(RuntimeError):
+    """eigamd_getrf_dev gave up because the device is shared (EIGAMD_ERR_NOT_RESIDENT): the matrix is partly
+    overwritten; restore it and call getrf_dev(..., shared=True)."""
+
+
+def getrf_dev(a, stream=None, max_block_size=256, transp=None, shared=False):
     """In-place LU of a DeviceMatrix.  Returns (transpositions as an int32 cuda tensor,
     nb_transpositions, first_zero_pivot).  max_block_size = 16 factorises `a` as one
-    panel of the blocked algorithm."""
+    panel of the blocked algorithm.  shared=True: eigamd_getrf_dev_shared, the form that needs no
+    workgroups resident together (for a device that other work is using)."""
     import torch
     from .device import _stream_ptr
     size = min(a.rows, a.cols)
     if transp is None:
         transp = torch.zeros(max(size, 1), dtype=torch.int32, device=a.storage.device)
     nb, fz = ctypes.c_int(0), ctypes.c_int(-1)
-    rc = lib.eigamd_getrf_dev(a.kind, a.rows, a.cols, ctypes.c_void_p(a.ptr), a.ld, ctypes.c_void_p(transp.data_ptr()),
-                              max_block_size, ctypes.byref(fz), ctypes.byref(nb), _stream_ptr(stream))
+    fn = lib.eigamd_getrf_dev_shared if shared else lib.eigamd_getrf_dev
+    rc = fn(a.kind, a.rows, a.cols, ctypes.c_void_p(a.ptr), a.ld, ctypes.c_void_p(transp.data_ptr()),
+            max_block_size, ctypes.byref(fz), ctypes.byref(nb), _stream_ptr(stream))
+    if rc == _lib.ERR_NOT_RESIDENT:
+        raise NotResident(lib.eigamd_last_error().decode())
     _lib.check(rc, "eigamd_getrf_dev")
     return transp[:size], nb.value, fz.value
 

@@ -27,7 +27,8 @@ enum {
   EIGAMD_OK = 0,
   EIGAMD_ERR_ARG = -1,     /* invalid argument (the F77 entry points call xerbla_ instead) */
   EIGAMD_ERR_DEVICE = -2,  /* HIP runtime error; eigamd_last_error() has the text */
-  EIGAMD_ERR_NO_GPU = -3   /* no gfx950 device visible: there is no CPU fallback */
+  EIGAMD_ERR_NO_GPU = -3,  /* no gfx950 device visible: there is no CPU fallback */
+  EIGAMD_ERR_NOT_RESIDENT = -4 /* eigamd_getrf_dev only, see there: the matrix is partly overwritten */
 };
 
 /* ---- F77 BLAS ABI, host pointers --------------------------------------------
@@ -198,7 +199,18 @@ int eigamd_fill_uniform_cyclic_dev(int dtype, void* d_x, int64_t rows, int64_t c
  * eigamd_getrf_dev factorises a matrix already in HBM; d_transp is device memory
  * (min(m,n) ints); max_block_size is blocked_lu's maxBlockSize argument (256 for a
  * whole matrix, 16 for one panel, PartialPivLU.h:429,472).  It synchronises `stream`
- * before returning the two counters. */
+ * before returning the two counters.
+ *
+ * Sharing the device: the kernel that factorises 16 columns of a tall panel in one launch needs all its
+ * workgroups on the device at the same time.  When kernels of other streams or processes hold the compute
+ * units, its workgroups give up after a bounded wait (about a second in all; nothing hangs) and
+ * eigamd_getrf_dev returns EIGAMD_ERR_NOT_RESIDENT.  d_a and d_transp then hold a factorisation that stopped
+ * part-way: columns left of the panel that gave up are final, the rest is neither the input nor the result.
+ * The caller restores d_a from its copy and calls eigamd_getrf_dev_shared, which factorises the same way
+ * (same pivots, same factors) with one launch per pivot column in place of that kernel, needs no residency
+ * and therefore never returns this code; it is the slower form (about 2x at 8192 x 8192) and the right first
+ * call for a process that knows it shares its GPU.  The host-pointer entries above (?getrf_,
+ * eigamd_blocked_lu_host*) still hold the caller's matrix and do exactly this by themselves. */
 int eigamd_blocked_lu_host(int dtype, int64_t rows, int64_t cols, void* lu, int64_t lu_stride,
                            int* row_transpositions, int* nb_transpositions, int* first_zero_pivot);
 /* The same for a matrix stored row by row (row stride lu_stride >= cols): what
@@ -219,9 +231,11 @@ int cgetrf_(const int* m, const int* n, void* a, const int* lda, int* ipiv, int*
 int zgetrf_(const int* m, const int* n, void* a, const int* lda, int* ipiv, int* info);   /* a: interleaved (re, im) doubles */
 int eigamd_getrf_dev(int dtype, int64_t m, int64_t n, void* d_a, int64_t lda, int* d_transp,
                      int64_t max_block_size, int* first_zero_pivot, int* nb_transpositions, void* stream);
+int eigamd_getrf_dev_shared(int dtype, int64_t m, int64_t n, void* d_a, int64_t lda, int* d_transp,
+                            int64_t max_block_size, int* first_zero_pivot, int* nb_transpositions, void* stream);
 /* The same without waiting (m, n >= 1): behind `stream`, the 3 ints at d_info (device memory) hold the first
  * zero pivot or -1, the number of row exchanges, and a status (0, or 1 where eigamd_getrf_dev would have
- * returned EIGAMD_ERR_DEVICE because the panel kernel's workgroups were not resident together).  For
+ * returned EIGAMD_ERR_NOT_RESIDENT).  For
  * drivers that keep the whole factorisation on the device (the multi-GPU LU). */
 int eigamd_getrf_dev_async(int dtype, int64_t m, int64_t n, void* d_a, int64_t lda, int* d_transp, int64_t max_block_size,
                            int* d_info, void* stream);

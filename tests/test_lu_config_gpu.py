@@ -188,6 +188,26 @@ def test_host_entry_runs_again_without_the_fused_base_case():
     assert nb1 == nb2 and r1 == r2 == -1
 
 
+def test_device_entry_reports_not_resident_and_the_shared_form_finishes_the_job():
+    """The device entry's contract for a shared GPU: EIGAMD_ERR_NOT_RESIDENT (code -4, a name of its own), the
+    matrix partly overwritten; the caller restores it and calls eigamd_getrf_dev_shared, which gives the oracle's
+    transpositions and factors and cannot return that code (the injected failure does not reach it)."""
+    import torch
+    from eigen_amd.device import DeviceMatrix
+    m, n = 1500, 1100
+    a = eigen_amd.fill_uniform_host(np.float64, m, n, 5 + m)
+    a1 = a.copy(order="F")
+    t1, nb1, r1 = oracle_lu(a1)
+    d = DeviceMatrix.from_numpy(a)
+    with env(EIGAMD_LU_INJECT_FUSED_FAILURE=1, EIGAMD_LU_SINGLE=0):
+        with pytest.raises(ealu.NotResident):
+            ealu.getrf_dev(d)
+        d = DeviceMatrix.from_numpy(a)   # the caller's copy
+        transp, nb2, r2 = ealu.getrf_dev(d, shared=True)
+    check_against_oracle(a, a1, t1, d.to_numpy(), transp.cpu().numpy(), exact_pivots=True)
+    assert nb1 == nb2 and r1 == r2 == -1
+
+
 def test_host_entry_beside_a_long_product_on_another_stream():
     """The device shared for real: a queue of large products on another stream fills every compute unit's
     registers while the factorisation runs.  Whether the one-launch base case still gets its workgroups
