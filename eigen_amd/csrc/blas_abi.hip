@@ -1139,7 +1139,7 @@ int eigamd_getrf_dev_shared(int dtype, int64_t m, int64_t n, void* d_a, int64_t 
 
 int eigamd_getrf_dev_async(int dtype, int64_t m, int64_t n, void* d_a, int64_t lda, int* d_transp, int64_t max_block_size,
                            int* d_info, void* stream) {
-  if (dtype != F32 && dtype != F64) return fail(EIGAMD_ERR_ARG, "the LU that does not wait supports the real kinds (f32, f64)");
+  if (dtype < 0 || dtype > 3) return fail(EIGAMD_ERR_ARG, "invalid dtype");
   if (m < 1 || n < 1 || lda < m || m > 0x7fffffff || n > 0x7fffffff || !d_info)
     return fail(EIGAMD_ERR_ARG, "invalid LU arguments");
   int rc = ensure_device();

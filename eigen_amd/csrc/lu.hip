@@ -49,8 +49,40 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-template <typename T> struct Candidate {
-  T val;    // |a|, or -1 for "no row"
+// The scalar of a factorisation is float, double or a complex number of either (the reference's blocked_lu is a
+// template over the scalar and is bound for all four, PartialPivLU_LAPACKE.h:74-79).  Cx<R> is the (re, im) pair as
+// the callers store it, with the arithmetic the kernels need; division is Smith's, which does not overflow where
+// |b|^2 would.  Everything below is written once over the scalar T; what is always real -- the size of a pivot
+// candidate (scalar_score_coeff_op, PartialPivLU.h:375), the growth of an inverse -- has the type Real<T>.
+template <typename R> struct alignas(2 * sizeof(R)) Cx {
+  R x, y;
+  Cx() = default;
+  __host__ __device__ constexpr Cx(R re) : x(re), y(0) {}
+  __host__ __device__ constexpr Cx(R re, R im) : x(re), y(im) {}
+};
+template <typename R> __device__ __forceinline__ Cx<R> operator+(Cx<R> a, Cx<R> b) { return {a.x + b.x, a.y + b.y}; }
+template <typename R> __device__ __forceinline__ Cx<R> operator-(Cx<R> a, Cx<R> b) { return {a.x - b.x, a.y - b.y}; }
+template <typename R> __device__ __forceinline__ Cx<R> operator-(Cx<R> a) { return {-a.x, -a.y}; }
+template <typename R> __device__ __forceinline__ Cx<R> operator*(Cx<R> a, Cx<R> b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+template <typename R> __device__ __forceinline__ Cx<R> operator/(Cx<R> a, Cx<R> b) {
+  if (fabs(b.x) >= fabs(b.y)) {
+    const R r = b.y / b.x, d = b.x + b.y * r;
+    return {(a.x + a.y * r) / d, (a.y - a.x * r) / d};
+  }
+  const R r = b.x / b.y, d = b.x * r + b.y;
+  return {(a.x * r + a.y) / d, (a.y * r - a.x) / d};
+}
+template <typename R> __device__ __forceinline__ Cx<R>& operator+=(Cx<R>& a, Cx<R> b) { a.x += b.x; a.y += b.y; return a; }
+template <typename R> __device__ __forceinline__ Cx<R>& operator-=(Cx<R>& a, Cx<R> b) { a.x -= b.x; a.y -= b.y; return a; }
+template <typename T> struct RealOf { using type = T; };
+template <typename R> struct RealOf<Cx<R>> { using type = R; };
+template <typename T> using Real = typename RealOf<T>::type;
+__device__ __forceinline__ float absval(float v) { return fabs(v); }
+__device__ __forceinline__ double absval(double v) { return fabs(v); }
+template <typename R> __device__ __forceinline__ R absval(Cx<R> v) { return hypot(v.x, v.y); }
+
+template <typename R> struct Candidate {
+  R val;    // |a|, or -1 for "no row"
   int row;  // row index relative to the sub-panel
 };
 
@@ -129,30 +161,31 @@ template <typename T> __device__ Candidate<T> block_best(T val, int row) {
 // partials[b] = best candidate of column `col` over rows [row_begin, rows) of block b.
 template <typename T>
 __global__ void lu_colmax(const T* __restrict__ P, int64_t ld, int row_begin, int rows, int col,
-                          Candidate<T>* __restrict__ partials) {
+                          Candidate<Real<T>>* __restrict__ partials) {
   const int r = row_begin + blockIdx.x * kRowsPerBlock + threadIdx.x;
-  T val = (T)-1;
-  if (r < rows) val = fabs(P[r + (int64_t)col * ld]);
-  const Candidate<T> c = block_best<T>(val, r);
+  Real<T> val = (Real<T>)-1;
+  if (r < rows) val = absval(P[r + (int64_t)col * ld]);
+  const Candidate<Real<T>> c = block_best<Real<T>>(val, r);
   if (threadIdx.x == 0) partials[blockIdx.x] = c;
 }
 
 // One wavefront: pick the pivot of column jj from the per-block candidates, record
 // the transposition, swap the two rows across the sub-panel, publish the pivot row.
 template <typename T>
-__global__ void lu_pivot(T* __restrict__ P, int64_t ld, int jbw, int jj, const Candidate<T>* __restrict__ partials,
+__global__ void lu_pivot(T* __restrict__ P, int64_t ld, int jbw, int jj, const Candidate<Real<T>>* __restrict__ partials,
                          int nparts, int* __restrict__ transp, int row_offset, int col_global,
                          Side<T>* __restrict__ side, int* __restrict__ first_zero, int* __restrict__ nswaps) {
+  using R = Real<T>;
   const int lane = threadIdx.x;
-  T val = (T)-1;
+  R val = (R)-1;
   int row = 0x7fffffff;
   for (int i = lane; i < nparts; i += 64) {
-    const Candidate<T> c = partials[i];
+    const Candidate<R> c = partials[i];
     if (better(c.val, c.row, val, row)) { val = c.val; row = c.row; }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
-    const T ov = __shfl_down(val, off, 64);
+    const R ov = __shfl_down(val, off, 64);
     const int orow = __shfl_down(row, off, 64);
     if (better(ov, orow, val, row)) { val = ov; row = orow; }
   }
@@ -160,9 +193,9 @@ __global__ void lu_pivot(T* __restrict__ P, int64_t ld, int jbw, int jj, const C
   row = __shfl(row, 0, 64);
   if (row == 0x7fffffff) {  // nothing comparable in the column (NaNs): no exchange, pivot = the diagonal entry
     row = jj;
-    val = (T)1;
+    val = (R)1;
   }
-  const bool zero = !(val != (T)0);  // exactly zero
+  const bool zero = !(val != (R)0);  // exactly zero
   if (lane == 0) {
     transp[0] = row_offset + row;
     if (zero) {
@@ -188,7 +221,7 @@ __global__ void lu_pivot(T* __restrict__ P, int64_t ld, int jbw, int jj, const C
 // sub-panel, and the candidate for the next column's pivot.
 template <typename T>
 __global__ void lu_update(T* __restrict__ P, int64_t ld, int rows, int jbw, int jj, const Side<T>* __restrict__ side,
-                          Candidate<T>* __restrict__ partials) {
+                          Candidate<Real<T>>* __restrict__ partials) {
   __shared__ T s_u[kMaxBase];
   __shared__ T s_pivot;
   __shared__ int s_zero;
@@ -196,7 +229,7 @@ __global__ void lu_update(T* __restrict__ P, int64_t ld, int rows, int jbw, int 
   if (threadIdx.x == 0) { s_pivot = side->pivot; s_zero = side->zero; }
   __syncthreads();
   const int r = jj + 1 + blockIdx.x * kRowsPerBlock + threadIdx.x;
-  T cand = (T)-1;
+  Real<T> cand = (Real<T>)-1;
   if (r < rows) {
     T l = P[r + (int64_t)jj * ld];
     if (!s_zero) {
@@ -207,11 +240,11 @@ __global__ void lu_update(T* __restrict__ P, int64_t ld, int rows, int jbw, int 
       T* dst = P + r + (int64_t)c * ld;
       const T x = *dst - l * s_u[c];
       *dst = x;
-      if (c == jj + 1) cand = fabs(x);
+      if (c == jj + 1) cand = absval(x);
     }
   }
   if (jj + 1 < jbw) {
-    const Candidate<T> c = block_best<T>(cand, r);
+    const Candidate<Real<T>> c = block_best<Real<T>>(cand, r);
     if (threadIdx.x == 0) partials[blockIdx.x] = c;
   }
 }
@@ -273,6 +306,7 @@ template <typename T> struct InvShared {
   T inv[kMaxBase][kMaxBase + 1];   // inv[j][i] = inv(L(rows, rows))(i, j)
 };
 static_assert(kInvChunk * (kMaxBase + 1) >= kMaxBase * 65, "m (16 x 65) lives where l was");
+static_assert(kMaxBase * 4 <= 64, "a wavefront publishes a row of the widest scalar with one store per lane");
 
 template <typename T, int BATCH = 8> __device__ __forceinline__ void inverse_rows_job(const InvJob<T> job, const int group, InvShared<T>& sh) {
   const int t = threadIdx.x, cl = t & 63, rg = t >> 6;
@@ -342,7 +376,7 @@ template <typename T, int BATCH = 8> __device__ __forceinline__ void inverse_row
         if (i < nr) {
           job.X[(r0 + i) + (int64_t)c * bs] = v[q];
           job.XT[c + (int64_t)(r0 + i) * bs] = v[q];
-          mx = abs_max2(mx, (double)v[q]);
+          mx = abs_max2(mx, (double)absval(v[q]));
         }
       }
     }
@@ -580,7 +614,7 @@ template <typename T> struct Words {
 #define EIGAMD_LU_SLOT_BYTES 1024
 #endif
 template <typename T> struct alignas(EIGAMD_LU_SLOT_BYTES) BaseSlot {
-  unsigned long long val[Words<T>::N];
+  unsigned long long val[Words<Real<T>>::N];
   unsigned long long row;
   unsigned long long data[kMaxBase * Words<T>::N];
 };
@@ -619,6 +653,9 @@ __device__ __forceinline__ unsigned value_word(double v, int i) {
   return i == 0 ? (unsigned)b : (unsigned)(b >> 32);
 }
 __device__ __forceinline__ unsigned value_word(float v, int) { return __float_as_uint(v); }
+template <typename R> __device__ __forceinline__ unsigned value_word(Cx<R> v, int i) {
+  return i < Words<R>::N ? value_word(v.x, i) : value_word(v.y, i - Words<R>::N);
+}
 // Reads one value; false while any of its words is not of generation G yet.
 __device__ __forceinline__ bool get_value(const unsigned long long* p, double& v, unsigned G) {
   const unsigned long long lo = coherent_load(p), hi = coherent_load(p + 1);
@@ -629,6 +666,11 @@ __device__ __forceinline__ bool get_value(const unsigned long long* p, float& v,
   const unsigned long long w = coherent_load(p);
   v = __uint_as_float((unsigned)w);
   return (unsigned)(w >> 32) == G;
+}
+
+template <typename R> __device__ __forceinline__ bool get_value(const unsigned long long* p, Cx<R>& v, unsigned G) {
+  const bool re = get_value(p, v.x, G), im = get_value(p + Words<R>::N, v.y, G);
+  return re && im;
 }
 
 // Largest |a| / smallest row over the workgroup, result in every thread.  One barrier; the
@@ -654,8 +696,11 @@ template <typename T> __device__ Candidate<T> block_best_all(T val, int row) {
 // workgroups have published, then every workgroup picks the same winner and the owners of
 // the two rows exchange them.  A workgroup that polls kSpinLimit times without success sets
 // *error and leaves; so does every workgroup that then sees the flag: the grid always drains.
+// (Four workgroups per compute unit for the real scalars; complex arithmetic needs more registers per row element
+// and gets the budget of two.)
+template <typename T> constexpr int fused_min_blocks() { return sizeof(Real<T>) != sizeof(T) ? 2 : 4; }
 template <typename T>
-__global__ void __launch_bounds__(kRowsPerBlock, 4)
+__global__ void __launch_bounds__(kRowsPerBlock, fused_min_blocks<T>())
     lu_base_fused(T* __restrict__ P, int64_t ld, int rows, int jbw, int size, int* __restrict__ transp,
                   int row_offset, int col_global, BaseSlot<T>* __restrict__ slots, BaseTop<T>* __restrict__ tops,
                   unsigned gen0, int* __restrict__ error, int* __restrict__ first_zero, int* __restrict__ nswaps, Ride<T> ride) {
@@ -663,7 +708,8 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
   __shared__ T s_top[kMaxBase];
   __shared__ unsigned s_pub[kRowsPerBlock / 64][kMaxBase * Words<T>::N];  // per wavefront: the words of the row it is about to publish
   __shared__ int s_win_row, s_flags;   // the winner's row; 1: the pivot is exactly zero, 2: gave up waiting
-  constexpr int NW = Words<T>::N;
+  constexpr int NW = Words<T>::N;          // words of a matrix element
+  constexpr int NV = Words<Real<T>>::N;    // words of a candidate's size
   // The last workgroups of the grid take no part in the factorisation: rows of the enclosing panel's inverse and
   // the far part of the block before's update (Ride), in the time the others spend on their sixteen exchanges.
   const int nparts = (int)gridDim.x - ride.inv_groups() - ride.far_groups();
@@ -702,13 +748,14 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
     // candidate of this workgroup for column jj ("no row" when all its rows are above jj)
     const T cur = row[jj];
     const bool cand = valid && r >= jj;
-    const Candidate<T> best = block_best_all<T>(cand ? (T)fabs(cur) : (T)-1, cand ? r : kNoRow);
+    const Candidate<Real<T>> best = block_best_all<Real<T>>(cand ? absval(cur) : (Real<T>)-1, cand ? r : kNoRow);
     const bool have = best.row != kNoRow;
     LU_TICK(0)
-    // The wavefront that holds the candidate's row publishes the slot with one store per lane:
-    // the lane of that row leaves it in LDS (same wavefront: LDS serves its accesses in order, no
-    // barrier needed), lanes [0, 16 NW) store its words, the next NW + 1 lanes |a| and the row
-    // index.  A workgroup without a candidate publishes "no row" from its first wavefront.
+    // The wavefront that holds the candidate's row publishes the slot with one store per lane (two for
+    // the few words that a row of complex doubles leaves over): the lane of that row leaves it in LDS (same
+    // wavefront: LDS serves its accesses in order, no barrier needed); of the slot's 16 NW + NV + 1 words, taken
+    // in the order data, |a|, row index, lane l stores word l (and l + 64).  A workgroup without a candidate
+    // publishes "no row" from its first wavefront.
     {
       const int win_local = have ? best.row - (int)blockIdx.x * kRowsPerBlock : 0;
       if ((win_local >> 6) == wave) {
@@ -721,21 +768,26 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
         }
         __builtin_amdgcn_wave_barrier();
         unsigned long long* mine = reinterpret_cast<unsigned long long*>(buf + blockIdx.x);
-        unsigned payload = 0;
-        int word = -1;  // index into the slot: val[NW], row, data[16 NW]
-        if (lane < kMaxBase * NW) {
-          if (have) {
-            payload = pub[lane];
-            word = NW + 1 + lane;
+        constexpr int kSlotWords = kMaxBase * NW + NV + 1;
+#pragma unroll
+        for (int round = 0; round < (kSlotWords + 63) / 64; ++round) {
+          const int e = lane + 64 * round;
+          unsigned payload = 0;
+          int word = -1;  // index into the slot: val[NV], row, data[16 NW]
+          if (e < kMaxBase * NW) {
+            if (have) {
+              payload = pub[e];
+              word = NV + 1 + e;
+            }
+          } else if (e < kMaxBase * NW + NV) {
+            payload = value_word(best.val, e - kMaxBase * NW);
+            word = e - kMaxBase * NW;
+          } else if (e == kSlotWords - 1) {
+            payload = (unsigned)best.row;
+            word = NV;
           }
-        } else if (lane < kMaxBase * NW + NW) {
-          payload = value_word(best.val, lane - kMaxBase * NW);
-          word = lane - kMaxBase * NW;
-        } else if (lane == kMaxBase * NW + NW) {
-          payload = (unsigned)best.row;
-          word = NW;
+          if (word >= 0) put_word(mine + word, payload, G);
         }
-        if (word >= 0) put_word(mine + word, payload, G);
         __builtin_amdgcn_wave_barrier();
       }
     }
@@ -749,7 +801,7 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
           for (int w = 0; w < NW; ++w) pub[c * NW + w] = value_word(row[c], w);
       }
       __builtin_amdgcn_wave_barrier();
-      if (lane < kMaxBase * NW) put_word(&top->data[lane], pub[lane], G);
+      if (lane < kMaxBase * NW) put_word(&top->data[lane], pub[lane], G);   // (16 NW <= 64)
       __builtin_amdgcn_wave_barrier();
     }
     // Wavefront 0 alone talks to the exchange area: it polls every workgroup's candidate of
@@ -758,7 +810,8 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
     // LDS.  No workgroup barrier sits inside a polling loop; the other wavefronts wait at one.
     LU_TICK(1)
     if (threadIdx.x < 64) {
-      T val = (T)-1;
+      using R = Real<T>;
+      R val = (R)-1;
       int prow = kNoRow;
       unsigned spins = 0;
       bool failed = false;
@@ -767,13 +820,13 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
       __builtin_amdgcn_s_sleep(EIGAMD_LU_POLL_DELAY);
       for (;;) {
         bool ready = true;
-        val = (T)-1;
+        val = (R)-1;
         prow = kNoRow;
 #ifdef EIGAMD_LU_TIMING
         ++poll_rounds;
 #endif
         for (int i = lane; i < nparts; i += 64) {
-          T v;
+          R v;
           const bool okv = get_value(buf[i].val, v, G);
           const unsigned long long w = coherent_load(&buf[i].row);
           if (!okv || (unsigned)(w >> 32) != G) {
@@ -796,9 +849,9 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
       prow = from_lane63(prow);
       if (prow == kNoRow) {  // nothing comparable in the column (NaNs): no exchange, pivot = the diagonal entry
         prow = jj;
-        val = (T)1;
+        val = (R)1;
       }
-      const bool zero_w = !(val != (T)0);  // exactly zero
+      const bool zero_w = !(val != (R)0);  // exactly zero
       const bool swap_w = !zero_w && prow != jj;
       if (!failed) {
         const unsigned long long* src_top = top->data;
@@ -839,7 +892,7 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
       alive = false;
     }
     if (alive) {
-    Candidate<T> win;
+    struct { int row; } win;
     win.row = s_win_row;
     const bool zero = (s_flags & 1) != 0;
     const bool swap = !zero && win.row != jj;
@@ -882,12 +935,16 @@ __global__ void __launch_bounds__(kRowsPerBlock, 4)
 #undef LU_TICK
 }
 
-// The same base case for panels of at most kSingleRows rows, in ONE workgroup of 1024 threads
-// with kSingleRpt rows per thread: the pivot search and the exchange of the two rows go through
+// The same base case for panels of at most single_rows() rows, in ONE workgroup of 1024 threads
+// with single_rpt() rows per thread: the pivot search and the exchange of the two rows go through
 // LDS and two workgroup barriers per column, no global memory and no other workgroup is involved
 // (a column costs about 1 us here against 3.5 us or more through the exchange area).  Same
 // arithmetic as lu_base_fused, operation for operation.
-constexpr int kSingleThreads = 1024, kSingleRpt = 2, kSingleRows = kSingleThreads * kSingleRpt;
+// (Two rows per thread for the real scalars, one for the complex ones: 16 waves on a compute unit have 128
+// registers each.)
+constexpr int kSingleThreads = 1024;
+template <typename T> constexpr int single_rpt() { return sizeof(Real<T>) != sizeof(T) ? 1 : 2; }
+template <typename T> constexpr int single_rows() { return kSingleThreads * single_rpt<T>(); }
 template <typename T>
 __global__ void __launch_bounds__(kSingleThreads)
     lu_base_single(T* __restrict__ P, int64_t ld, int rows, int jbw, int size, int* __restrict__ transp, int row_offset,
@@ -898,7 +955,9 @@ __global__ void __launch_bounds__(kSingleThreads)
   }
   __shared__ T s_u[kMaxBase];
   __shared__ T s_top[kMaxBase];
-  __shared__ T s_val[kSingleThreads / 64];
+  using R = Real<T>;
+  constexpr int kSingleRpt = single_rpt<T>();
+  __shared__ R s_val[kSingleThreads / 64];
   __shared__ int s_row[kSingleThreads / 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   // row[q][c]: element c of row tid + q * 1024.  The loop over the pivot columns is unrolled in full,
@@ -914,13 +973,13 @@ __global__ void __launch_bounds__(kSingleThreads)
   static_for<kMaxBase>([&](auto jj_c) {
     constexpr int jj = decltype(jj_c)::value;
     if (jj < size) {
-      T val = (T)-1;
+      R val = (R)-1;
       int prow = kNoRow;
 #pragma unroll
       for (int q = 0; q < kSingleRpt; ++q) {
         const int r = tid + q * kSingleThreads;
         if (r < rows && r >= jj) {
-          const T v = (T)fabs(row[q][jj]);
+          const R v = absval(row[q][jj]);
           if (better(v, r, val, prow)) { val = v; prow = r; }
         }
       }
@@ -934,9 +993,9 @@ __global__ void __launch_bounds__(kSingleThreads)
         if (better(s_val[w], s_row[w], val, prow)) { val = s_val[w]; prow = s_row[w]; }
       if (prow == kNoRow) {  // nothing comparable in the column (NaNs): no exchange, pivot = the diagonal entry
         prow = jj;
-        val = (T)1;
+        val = (R)1;
       }
-      const bool zero = !(val != (T)0);  // exactly zero
+      const bool zero = !(val != (R)0);  // exactly zero
       const bool swap = !zero && prow != jj;
       // the pivot row (what every row below is updated with) and, for an exchange, panel row jj
 #pragma unroll
@@ -1172,6 +1231,11 @@ __global__ void __launch_bounds__(kPlanSpan) lu_swap_plan(const int* __restrict_
 // has completed before any of its stores is issued: a row may be the source of one move and the destination of
 // another.
 constexpr int kPlanCols = 16;
+// (Kernels that only move elements take a complex one as a two-element vector of the hardware: a plain register pair.)
+template <typename T> struct RawOf { using type = T; };
+template <> struct RawOf<Cx<float>> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct RawOf<Cx<double>> { typedef double type __attribute__((ext_vector_type(2))); };
+template <typename T> using Raw = typename RawOf<T>::type;
 template <typename T>
 __global__ void __launch_bounds__(256) lu_apply_plan(T* __restrict__ A, int64_t ld, int ncols, const SwapPlan* __restrict__ plan) {
   const int n = plan->count;
@@ -1297,7 +1361,7 @@ __global__ void __launch_bounds__(256) lu_trtri(const T* __restrict__ L, int64_t
     const int c = idx / bs, i = idx % bs;
     if (first + c < bs) {
       X[i + (int64_t)(first + c) * bs] = s_x[c][i];
-      mx = abs_max2(mx, (double)s_x[c][i]);
+      mx = abs_max2(mx, (double)absval(s_x[c][i]));
     }
   }
   note_inverse_max(gmax, mx);
@@ -1339,7 +1403,7 @@ __global__ void __launch_bounds__(64) lu_trtri_diag(const T* __restrict__ L, int
 #pragma unroll
     for (int ii = 0; ii < kInvCols; ++ii) {
       col[first + ii] = x[ii];
-      mx = abs_max2(mx, (double)x[ii]);
+      mx = abs_max2(mx, (double)absval(x[ii]));
     }
   }
   note_inverse_max(gmax, mx);  // (outside the branch: the shuffles of the reduction involve every lane)
@@ -1468,7 +1532,7 @@ __global__ void __launch_bounds__(256) lu_trtri_merge(const T* __restrict__ L, i
         const int j = base + 2 * tj + 32 * m + e;
         X[(r0 + ti) + (int64_t)j * bs] = -acc[0][2 * m + e];
         X[(r0 + ti + 16) + (int64_t)j * bs] = -acc[1][2 * m + e];
-        mx = abs_max2(abs_max2(mx, (double)acc[0][2 * m + e]), (double)acc[1][2 * m + e]);
+        mx = abs_max2(abs_max2(mx, (double)absval(acc[0][2 * m + e])), (double)absval(acc[1][2 * m + e]));
       }
     }
   }
@@ -1573,6 +1637,16 @@ __global__ void __launch_bounds__(256) lu_subst_flagged(const int* __restrict__ 
 template <typename T> struct KindOf;
 template <> struct KindOf<float> { static constexpr int value = F32; };
 template <> struct KindOf<double> { static constexpr int value = F64; };
+template <> struct KindOf<Cx<float>> { static constexpr int value = C32; };
+template <> struct KindOf<Cx<double>> { static constexpr int value = C64; };
+inline hipError_t launch_product(const GemmCall& c, hipStream_t s) {
+  switch (c.kind) {
+    case F32: return launch_gemm_f32(c, s);
+    case F64: return launch_gemm_f64(c, s);
+    case C32: return launch_gemm_c32(c, s);
+    default:  return launch_gemm_c64(c, s);
+  }
+}
 
 template <typename T> hipError_t gemm_minus3(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B,
                                              int64_t ldb, T* C, int64_t ldc, hipStream_t s);
@@ -1595,18 +1669,19 @@ template <typename T> hipError_t gemm_minus3(int64_t m, int64_t n, int64_t k, co
   c.opa = OP_N; c.opb = OP_N;
   c.m = m; c.n = n; c.k = k;
   c.serial_edges = true;   // the look-ahead owns the CU split between its streams
-  c.atomic_c = atomic_updates_enabled() && k >= 512;  // (a k = 256 product is bound by the rate of the atomic adds: 53 against 55 TFLOP/s)
+  // (a k = 256 product is bound by the rate of the atomic adds: 53 against 55 TFLOP/s; real scalars only)
+  c.atomic_c = atomic_updates_enabled() && k >= 512 && sizeof(Real<T>) == sizeof(T);
   c.alpha[0] = -1.0; c.alpha[1] = 0.0;
   c.beta[0] = 1.0; c.beta[1] = 0.0;
   c.A = A; c.lda = lda;
   c.B = B; c.ldb = ldb;
   c.C = C; c.ldc = ldc;
-  return KindOf<T>::value == F64 ? launch_gemm_f64(c, s) : launch_gemm_f32(c, s);
+  return launch_product(c, s);
 }
 
-// C = A * B (alpha = 1, beta = 0).
+// C = A * B + beta * C (alpha = 1; beta = 0 or 1).
 template <typename T> hipError_t gemm_assign(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B, int64_t ldb,
-                                             T* C, int64_t ldc, hipStream_t s) {
+                                             T* C, int64_t ldc, hipStream_t s, double beta = 0.0) {
   if (m <= 0 || n <= 0) return hipSuccess;
   GemmCall c;
   c.kind = KindOf<T>::value;
@@ -1614,11 +1689,11 @@ template <typename T> hipError_t gemm_assign(int64_t m, int64_t n, int64_t k, co
   c.m = m; c.n = n; c.k = k;
   c.serial_edges = true;
   c.alpha[0] = 1.0; c.alpha[1] = 0.0;
-  c.beta[0] = 0.0; c.beta[1] = 0.0;
+  c.beta[0] = beta; c.beta[1] = 0.0;
   c.A = A; c.lda = lda;
   c.B = B; c.ldb = ldb;
   c.C = C; c.ldc = ldc;
-  return KindOf<T>::value == F64 ? launch_gemm_f64(c, s) : launch_gemm_f32(c, s);
+  return launch_product(c, s);
 }
 
 int block_size_rule(int64_t size, int64_t max_block) {  // PartialPivLU.h:443-448
@@ -1656,7 +1731,7 @@ template <typename T> struct InverseTarget {
 };
 
 template <typename T> struct Workspace {
-  Candidate<T>* partials;
+  Candidate<Real<T>>* partials;
   Side<T>* side;
   int* first_zero;
   int* nswaps;
@@ -1693,7 +1768,7 @@ hipError_t unblocked(T* P, int64_t ld, int64_t rows, int jbw, int* transp, int r
   const int size = (int)std::min<int64_t>(rows, jbw);
   int nparts = (int)((rows + kRowsPerBlock - 1) / kRowsPerBlock);
   const int njob = ride.inv_groups() + ride.far_groups();   // extra workgroups at the end of the grid (they wait for nobody)
-  if (rows <= kSingleRows && w.rule.single) {
+  if (rows <= single_rows<T>() && w.rule.single) {
     hipLaunchKernelGGL(lu_base_single<T>, dim3(1 + njob), dim3(kSingleThreads), 0, s, P, ld, (int)rows, jbw, size, transp,
                        row_offset, col_offset, w.first_zero, w.nswaps, ride);
     return hipGetLastError();
@@ -1727,8 +1802,8 @@ hipError_t make_plan(const int* transp, int k0, int k1, SwapPlan* plan, hipStrea
 }
 template <typename T> hipError_t apply_plan(T* A, int64_t ld, int64_t ncols, const SwapPlan* plan, hipStream_t s) {
   if (ncols <= 0) return hipSuccess;
-  hipLaunchKernelGGL(lu_apply_plan<T>, dim3((unsigned)((ncols + kPlanCols - 1) / kPlanCols)), dim3(256), 0, s, A, ld,
-                     (int)ncols, plan);
+  hipLaunchKernelGGL(lu_apply_plan<Raw<T>>, dim3((unsigned)((ncols + kPlanCols - 1) / kPlanCols)), dim3(256), 0, s,
+                     reinterpret_cast<Raw<T>*>(A), ld, (int)ncols, plan);
   return hipGetLastError();
 }
 
@@ -1738,7 +1813,8 @@ template <typename T>
 hipError_t laswp(T* A, int64_t ld, int64_t ncols, const int* transp, int k0, int k1, SwapPlan* plan, hipStream_t s) {
   if (ncols <= 0 || k1 <= k0) return hipSuccess;
   if (k1 - k0 <= 32 || plan == nullptr) {
-    hipLaunchKernelGGL(lu_laswp<T>, dim3((unsigned)((ncols + 127) / 128)), dim3(128), 0, s, A, ld, (int)ncols, transp, k0, k1);
+    hipLaunchKernelGGL(lu_laswp<Raw<T>>, dim3((unsigned)((ncols + 127) / 128)), dim3(128), 0, s, reinterpret_cast<Raw<T>*>(A), ld,
+                       (int)ncols, transp, k0, k1);
     return hipGetLastError();
   }
   for (int k = k0; k < k1; k += kPlanSpan) {
@@ -1779,15 +1855,20 @@ inline bool recursive_inverse_enabled() {
   }();
   return on;
 }
+// (lu_trtri keeps 32 whole columns of X in LDS, which complex doubles do not fit: they take the recursion, and
+// inverse_applies() admits no other width for them.)
+template <typename T> constexpr bool one_launch_inverse_fits() { return sizeof(T) <= 8; }
 template <typename T>
 hipError_t make_inverse(const T* L, int64_t ldl, int64_t bs, T* X, int* flag, unsigned long long* gmax, double limit,
                         hipStream_t s) {
-  if ((bs == 64 || bs == 128 || bs == 256) && recursive_inverse_enabled()) {
+  if ((bs == 64 || bs == 128 || bs == 256) && (recursive_inverse_enabled() || !one_launch_inverse_fits<T>())) {
     hipLaunchKernelGGL(lu_trtri_diag<T>, dim3((unsigned)(bs / kInvCols)), dim3(64), 0, s, L, ldl, (int)bs, X, gmax);
     for (int h = kInvCols; h < bs; h *= 2)
       hipLaunchKernelGGL(lu_trtri_merge<T>, dim3((unsigned)(bs / 64)), dim3(256), 0, s, L, ldl, (int)bs, h, X, gmax);
-  } else {
+  } else if constexpr (one_launch_inverse_fits<T>()) {
     hipLaunchKernelGGL(lu_trtri<T>, dim3((unsigned)((bs + kInvCols - 1) / kInvCols)), dim3(256), 0, s, L, ldl, (int)bs, X, gmax);
+  } else {
+    return hipErrorInvalidValue;
   }
   hipLaunchKernelGGL(lu_inverse_finish<T>, dim3(1), dim3(256), 0, s, X, (int)bs, limit, gmax, flag);
   return hipGetLastError();
@@ -1813,7 +1894,12 @@ inline bool incremental_inverse_enabled() {   // EIGAMD_LU_INVERSE_ON_THE_WAY=0:
   }();
   return on;
 }
-template <typename T> bool inverse_applies(int64_t bs) { return bs > 32 && bs <= kPlanSpan && bs <= gemm_tile_rows<T>(); }
+// (A block taller than one tile row of the kind's product -- complex: 128 -- is multiplied in two halves, see
+// apply_inverse; hence up to two tile rows.)
+template <typename T> bool inverse_applies(int64_t bs) {
+  if (!one_launch_inverse_fits<T>() && bs != 64 && bs != 128 && bs != 256) return false;
+  return bs > 32 && bs <= kPlanSpan && bs <= 2 * gemm_tile_rows<T>();
+}
 // With `out` the product goes there instead (leading dimension ldo): a product that does not overwrite its operand may
 // run on any tile, and a block of few columns then spreads over many compute units instead of two large tiles.
 template <typename T>
@@ -1824,7 +1910,13 @@ hipError_t apply_inverse(const T* X, const int* flag, const T* L, int64_t ldl, i
                      (int)ncols);
   LU_TRY(hipGetLastError());
   if (out) return gemm_assign<T>(bs, ncols, bs, X, bs, B, ldb, out, ldo, s);
-  return gemm_assign<T>(bs, ncols, bs, X, bs, B, ldb, B, ldb, s);
+  const int64_t h = gemm_tile_rows<T>();
+  if (bs <= h) return gemm_assign<T>(bs, ncols, bs, X, bs, B, ldb, B, ldb, s);
+  // Two tile rows, in place: with X = [X11 0; X21 X22] and B = [B1; B2], first B2 <- X22 B2 (one tile row, in place),
+  // then B2 += X21 B1 (B1 still holds the operand), then B1 <- X11 B1.
+  LU_TRY(gemm_assign<T>(bs - h, ncols, bs - h, X + h + h * bs, bs, B + h, ldb, B + h, ldb, s));
+  LU_TRY(gemm_assign<T>(bs - h, ncols, h, X + h, bs, B, ldb, B + h, ldb, s, 1.0));
+  return gemm_assign<T>(h, ncols, h, X, bs, B, ldb, B, ldb, s);
 }
 
 // blocked_lu (PartialPivLU.h:429-498).  A points at the (row0, row0) corner of the
@@ -2078,14 +2170,16 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
     InverseTarget<T> targets[kMaxSub];
     for (int i = 0; i < nsub; ++i) targets[i] = {linv[i], linv_flag[i], w.linv_max[par * kMaxSub + i], w.linvT[par * kMaxSub + i], plan[i]};
     const bool on_the_way = incremental_inverse_enabled() && trows > 0 && planned;
+    // (pieces_inverted: the plans and inverses of ALL the step's pieces come out of this call)
+    bool pieces_inverted;
     if (bs > rule_block) {
-      LU_TRY(blocked<T>(A, ld, k, k, trows + bs, bs, transp, 16, w, pan, rule_block, on_the_way && rule_block == kPlanSpan ? targets : nullptr));
+      pieces_inverted = on_the_way && rule_block == kPlanSpan && inverse_applies<T>(rule_block);
+      LU_TRY(blocked<T>(A, ld, k, k, trows + bs, bs, transp, 16, w, pan, rule_block, pieces_inverted ? targets : nullptr));
     } else {
       // (one piece: this call is the panel level itself)
-      const bool direct = on_the_way && inverse_applies<T>(bs);
-      LU_TRY(blocked<T>(A, ld, k, k, trows + bs, bs, transp, 16, w, pan, 0, direct ? targets : nullptr));
+      pieces_inverted = on_the_way && inverse_applies<T>(bs);
+      LU_TRY(blocked<T>(A, ld, k, k, trows + bs, bs, transp, 16, w, pan, 0, pieces_inverted ? targets : nullptr));
     }
-    const bool pieces_inverted = on_the_way && (bs > rule_block ? rule_block == kPlanSpan : true);
     if (planned && !pieces_inverted)   // (otherwise the plans came with the inverses)
       for (int i = 0; i < nsub; ++i)
         LU_TRY(make_plan(transp, (int)(k + sub_begin(i)), (int)(k + sub_begin(i) + sub_size(i)), plan[i], pan));
@@ -2338,7 +2432,7 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   const size_t off_linvT = off_linv + kSets * round64((size_t)kPlanSpan * kPlanSpan * sizeof(T));
   const size_t off_solve = off_linvT + kSets * round64((size_t)kPlanSpan * kPlanSpan * sizeof(T));
   const size_t off_partials = off_solve + round64((size_t)kMaxSub * kPlanSpan * kMaxSub * kPlanSpan * sizeof(T));
-  const size_t need = off_partials + round64(nparts * sizeof(Candidate<T>));
+  const size_t need = off_partials + round64(nparts * sizeof(Candidate<Real<T>>));
   if (!sc.buf_done) LU_TRY(hipEventCreateWithFlags(&sc.buf_done, hipEventDisableTiming));
   if (sc.buf_busy) {
     if (need > sc.cap) LU_TRY(hipEventSynchronize(sc.buf_done));  // (the buffer is about to be freed)
@@ -2404,7 +2498,7 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   static_assert(128 + kSets * 8 <= 208 && 208 + kRankCounters * 4 <= 256 && (kPlanSpan + kRankCols - 1) / kRankCols <= kRankCounters,
                 "the counters of lu_rowops_rank_update must fit the header and cover a panel of the look-ahead");
   w.solve_tmp = reinterpret_cast<T*>(p + off_solve);
-  w.partials = reinterpret_cast<Candidate<T>*>(p + off_partials);
+  w.partials = reinterpret_cast<Candidate<Real<T>>*>(p + off_partials);
   w.slots = reinterpret_cast<BaseSlot<T>*>(p + off_slots);
   LU_TRY(hipMemsetAsync(p, 0, 256, s));  // error flag of the fused base case, inverse flags and maxima
   LU_TRY(hipMemsetAsync(w.first_zero, 0xFF, sizeof(int), s));  // -1
@@ -2470,8 +2564,12 @@ hipError_t getrf_device(int kind, int64_t m, int64_t n, void* A, int64_t ld, int
   if (kind == F32)
     return getrf_device_t<float>(m, n, static_cast<float*>(A), ld, d_transp, max_block, first_zero_pivot,
                                  nb_transpositions, s, allow_fused, d_info);
-  if ((kind == C32 || kind == C64) && !d_info)  // the complex driver has no one-launch base case: nothing to turn off
-    return getrf_device_complex(kind, m, n, A, ld, d_transp, max_block, first_zero_pivot, nb_transpositions, s);
+  if (kind == C64)
+    return getrf_device_t<Cx<double>>(m, n, static_cast<Cx<double>*>(A), ld, d_transp, max_block, first_zero_pivot,
+                                      nb_transpositions, s, allow_fused, d_info);
+  if (kind == C32)
+    return getrf_device_t<Cx<float>>(m, n, static_cast<Cx<float>*>(A), ld, d_transp, max_block, first_zero_pivot,
+                                     nb_transpositions, s, allow_fused, d_info);
   return hipErrorInvalidValue;
 }
 

@@ -23,10 +23,7 @@ hipError_t getrf_device(int kind, int64_t m, int64_t n, void* A, int64_t ld, int
 // With d_info (device memory, 3 ints) the call does not wait: behind `s`, d_info holds the first zero
 // pivot or -1, the number of exchanges, and 1 where the call without it would return kLuNotResident.
 
-// The complex kinds (C32, C64) go through a plainer driver (zlu.hip): same algorithm and block rule, per-column
-// kernels for the base case, one stream, no variant that does not wait (d_info must be null for them).
-hipError_t getrf_device_complex(int kind, int64_t m, int64_t n, void* A, int64_t ld, int* d_transp, int64_t max_block,
-                                int* first_zero_pivot, int* nb_transpositions, hipStream_t s);
+// (One driver for the four kinds: the complex ones are the same kernels over a (re, im) scalar.)
 
 // Row transpositions i <-> d_transp[i], i in [k0, k1), on ncols columns starting at A
 // (row indices are rows of A).

@@ -221,8 +221,7 @@ int eigamd_blocked_lu_host(int dtype, int64_t rows, int64_t cols, void* lu, int6
  * Complex kinds: the reference's blocked_lu is a template and its bindings include cgetrf / zgetrf
  * (PartialPivLU_LAPACKE.h:77-78, lapack/complex_single.cpp, complex_double.cpp).  All the LU entry points
  * here take the four kinds; the pivot of a complex column is its first entry of largest modulus
- * (scalar_score_coeff_op, PartialPivLU.h:375).  The complex kinds run a plainer driver than the real ones
- * (per-column kernels, one stream); eigamd_getrf_dev_async is for the real kinds only. */
+ * (scalar_score_coeff_op, PartialPivLU.h:375).  One driver serves the four kinds. */
 int eigamd_blocked_lu_host_rowmajor(int dtype, int64_t rows, int64_t cols, void* lu, int64_t lu_stride,
                                     int* row_transpositions, int* nb_transpositions, int* first_zero_pivot);
 int dgetrf_(const int* m, const int* n, double* a, const int* lda, int* ipiv, int* info);

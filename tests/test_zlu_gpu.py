@@ -1,6 +1,6 @@
-"""Parity of the complex device LU (eigen_amd/csrc/zlu.hip, through the C ABI) with the LU oracle,
-which is pinned against the reference's partial_lu_impl<std::complex<..>>::blocked_lu in
-test_lu_oracle.py.  Same rule and tolerances as for the real kinds (lu_checks.py): identical
+"""Parity of the device LU for the complex kinds (eigen_amd/csrc/lu.hip instantiated over a (re, im) scalar,
+through the C ABI) with the LU oracle, which is pinned against the reference's
+partial_lu_impl<std::complex<..>>::blocked_lu in test_lu_oracle.py.  Same rule and tolerances as for the real kinds (lu_checks.py): identical
 transpositions for complex128, identical up to a near-tie for complex64,
 max|LU_gpu - LU_oracle| <= 64 * eps * n * max|LU|, ||P*A - L*U||_F <= 8 * eps * n * ||A||_F."""
 import ctypes
@@ -12,6 +12,7 @@ import oracle_lib as ol
 import eigen_amd
 from eigen_amd import lu as ealu
 from lu_checks import check_against_oracle, check_structure, residual
+from test_lu_config_gpu import env
 from test_lu_oracle import SHAPES, oracle_lu, random_matrix
 
 pytestmark = pytest.mark.gpu
@@ -87,3 +88,83 @@ def test_device_resident_4096(dt):
     t = transp.cpu().numpy()
     check_structure(lu, t, n, n)
     assert residual(a0, lu, t) <= 8 * np.finfo(dt).eps * n
+
+
+# Every base case and every switch of the driver, for the complex scalars: the per-column kernel chain, the one-launch
+# base case on short panels, the inverse built behind the panel, in-place solves of the next block's columns, the far
+# part of a block's update as a launch of its own, row operations and rank update as two launches, substitution in
+# place of every inverse, forced wide outer steps, the trailing update on two streams.
+SWITCHES = [dict(EIGAMD_LU_FUSED=0, EIGAMD_LU_SINGLE=0), dict(EIGAMD_LU_SINGLE=0), dict(EIGAMD_LU_INVERSE_ON_THE_WAY=0),
+            dict(EIGAMD_LU_SOLVE_TMP=0), dict(EIGAMD_LU_FAR_RIDES=0), dict(EIGAMD_LU_FUSED_ROWOPS=0),
+            dict(EIGAMD_LU_INVERSE_LIMIT=0), dict(EIGAMD_LU_WIDE=512), dict(EIGAMD_LU_SPLIT_MIN=256, EIGAMD_LU_WIDE=256)]
+
+
+_ORACLE = {}
+
+
+def matrix_and_oracle(dt, m, n):
+    """(matrix, oracle's factors, transpositions, exchanges, first zero pivot), worked out once per kind and shape."""
+    if (dt, m, n) not in _ORACLE:
+        a = random_matrix(np.random.default_rng(17 * m + n), (m, n), dt).copy(order="F")
+        a1 = a.copy(order="F")
+        _ORACLE[(dt, m, n)] = (a, a1) + tuple(oracle_lu(a1))
+    return _ORACLE[(dt, m, n)]
+
+
+@pytest.mark.parametrize("dt", KINDS)
+@pytest.mark.parametrize("knobs", SWITCHES, ids=lambda k: ",".join(f"{a[10:]}={b}" for a, b in k.items()))
+def test_driver_switches_vs_oracle(dt, knobs):
+    for (m, n) in [(2304, 2304), (1500, 1100)]:
+        a, a1, t1, nb1, r1 = matrix_and_oracle(dt, m, n)
+        a2 = a.copy(order="F")
+        with env(**knobs):
+            t2, nb2, r2 = ealu.blocked_lu(a2)
+        assert r1 == r2 == -1
+        if check_against_oracle(a, a1, t1, a2, t2, exact_pivots=dt == np.complex128) is None:
+            assert nb1 == nb2
+
+
+@pytest.mark.parametrize("dt", KINDS)
+@pytest.mark.parametrize("knobs", [dict(EIGAMD_LU_FUSED=0, EIGAMD_LU_SINGLE=0), dict(EIGAMD_LU_SINGLE=0), dict()])
+def test_column_of_nans_takes_the_diagonal_entry(dt, knobs):
+    n = 600
+    a = random_matrix(np.random.default_rng(5), (n, n), dt).copy(order="F")
+    a[:, 5] = np.nan
+    with env(**knobs):
+        t, nb, fz = ealu.blocked_lu(a)
+    assert t[5] == 5 and (t >= np.arange(n)).all() and (t < n).all()
+
+
+@pytest.mark.parametrize("dt", KINDS)
+def test_entry_that_does_not_wait_and_the_shared_form(dt):
+    """eigamd_getrf_dev_async and eigamd_getrf_dev_shared take the complex kinds as they take the real ones."""
+    import torch
+    from eigen_amd.device import DeviceMatrix
+    m, n = 1300, 1300
+    a = random_matrix(np.random.default_rng(11), (m, n), dt).copy(order="F")
+    a1 = a.copy(order="F")
+    t1, nb1, r1 = oracle_lu(a1)
+    d = DeviceMatrix.from_numpy(a)
+    transp = torch.zeros(n, dtype=torch.int32, device="cuda")
+    info = torch.zeros(3, dtype=torch.int32, device="cuda")
+    ealu.getrf_dev_async(d, transp, info)
+    torch.cuda.synchronize()
+    fz, nb, status = info.cpu().tolist()
+    assert (fz, status) == (-1, 0)
+    if check_against_oracle(a, a1, t1, d.to_numpy(), transp.cpu().numpy(), exact_pivots=dt == np.complex128) is None:
+        assert nb == nb1
+    d2 = DeviceMatrix.from_numpy(a)
+    t2, nb2, fz2 = ealu.getrf_dev(d2, shared=True)
+    assert fz2 == -1
+    check_against_oracle(a, a1, t1, d2.to_numpy(), t2.cpu().numpy(), exact_pivots=dt == np.complex128)
+
+
+def test_tall_panel_through_the_exchange_area():
+    """Enough rows that a panel's base case is the one-launch kernel with many workgroups (complex128: 5000 rows = 20)."""
+    m, n = 5000, 300
+    a = random_matrix(np.random.default_rng(23), (m, n), np.complex128).copy(order="F")
+    a1, a2 = a.copy(order="F"), a.copy(order="F")
+    t1, nb1, r1 = oracle_lu(a1)
+    t2, nb2, r2 = ealu.blocked_lu(a2)
+    check_against_oracle(a, a1, t1, a2, t2, exact_pivots=True)
+    assert nb1 == nb2 and r1 == r2 == -1

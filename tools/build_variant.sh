@@ -9,7 +9,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/build/variants/$name
 mkdir -p $out/obj
 cd $root/eigen_amd/csrc
-for f in gemm_inst_f32 gemm_inst_f32s gemm_inst_f64 gemm_inst_f64s gemm_inst_c32 gemm_inst_c32s gemm_inst_c64 gemm_inst_c64s lu zlu trsm syrk level3x pgemm xfer blas_abi; do
+for f in gemm_inst_f32 gemm_inst_f32s gemm_inst_f64 gemm_inst_f64s gemm_inst_c32 gemm_inst_c32s gemm_inst_c64 gemm_inst_c64s lu trsm syrk level3x pgemm xfer blas_abi; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function $flags -c $f.hip -o $out/obj/$f.o &
 done
 wait
