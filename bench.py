@@ -311,6 +311,53 @@ def lu_measurement(n):
     return out
 
 
+def lu_sweep_measurements():
+    """eigamd_getrf_dev below the configured size, where the factorisation is the panel chain alone, and for the other
+    kinds (best of 2; 2/3 n^3 flop, 8/3 n^3 for the complex kinds), each with the residual check of test/lu.cpp:168 on
+    sampled block rows done in complex128 / float64 on the device."""
+    import numpy as np
+    import torch
+    import eigen_amd
+    from eigen_amd.device import DeviceMatrix
+    from eigen_amd import lu as ealu
+    out = {}
+    for dtype, n in (("f64", 8192), ("f64", 16384), ("f32", 8192), ("c64", 8192), ("c32", 8192)):
+        kind = KIND[dtype]
+        a = DeviceMatrix(n, n, kind)
+        best = 1e30
+        for _ in range(2):
+            a.fill_uniform(77)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            transp, _, first_zero = ealu.getrf_dev(a)
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        t = transp.cpu().numpy()
+        perm = np.arange(n)
+        for i, p in enumerate(t):
+            if p != i:
+                perm[i], perm[p] = perm[p], perm[i]
+        wide = torch.complex128 if kind >= 2 else torch.float64
+        lu = a.as_strided()
+        a0 = DeviceMatrix(n, n, kind).fill_uniform(77).as_strided()
+        u = torch.triu(lu).to(wide)
+        cols = torch.arange(n, device="cuda")
+        worst, block = 0.0, 128
+        for r0 in (0, n // 2 + 64, n - block):
+            rows = torch.arange(r0, r0 + block, device="cuda")
+            lr = torch.where(cols[None, :] < rows[:, None], lu[rows], torch.zeros((), dtype=lu.dtype, device="cuda")).to(wide)
+            lr[torch.arange(block, device="cuda"), rows] = 1.0
+            pa = a0[torch.as_tensor(perm[r0:r0 + block], device="cuda")].to(wide)
+            worst = max(worst, float(torch.linalg.norm(pa - lr @ u) / torch.linalg.norm(pa)))
+        eps = 2.0 ** (-52 if dtype in ("f64", "c64") else -23)
+        name = f"{BLAS_LETTER[dtype]}getrf_{n}"
+        out[f"{name}_ms"] = round(best * 1e3, 2)
+        out[f"{name}_tflops"] = round((8.0 if kind >= 2 else 2.0) / 3.0 * n ** 3 / best / 1e12, 2)
+        out[f"{name}_checks_ok"] = bool(first_zero == -1 and (t >= np.arange(n)).all() and (t < n).all() and worst <= 8 * eps * n)
+        del a, a0, u, lu
+    return out
+
+
 def variant_measurements():
     """Device-resident C += op(A)*op(B) at the configured sizes for the transpose / conjugate forms
     (TFLOP/s, best of 3): dgemm / sgemm 16384^3 NN TN NT TT, zgemm / cgemm 8192^3 NN TN NC CC."""
@@ -577,6 +624,7 @@ def main():
                     "cgemm_8192_tflops": side_measurement("c32", 8192, 3),
                 }
                 out["extra"].update(lu_measurement(32768))
+                out["extra"].update(lu_sweep_measurements())
                 out["extra"].update(trsm_measurement(16384))
                 out["extra"].update(syrk_measurement(16384))
                 out["extra"].update(trmm_measurement(16384))

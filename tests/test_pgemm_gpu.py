@@ -126,35 +126,3 @@ def test_beta_zero_never_reads_c():
     got = np.full((m, n), np.nan, order="F")
     pgemm_host("N", "N", 0.7, a, b, 0.0, got, 2, 2, 128, devices=[0] * 4)
     assert ratio(kind, got, want, 0.7, a, b, 0.0, np.zeros((m, n), order="F")) < RATIO_LIMIT
-
-
-def test_host_route_over_a_grid_overlaps_its_copies_with_its_products():
-    """Four ranks on the one device share its host link, so what the grid's host route can gain or lose against the
-    single-device host route is overlap alone: operands uploaded in the order the reduction consumes them, the
-    products underneath the later uploads, C back as soon as the last product has run.  Within 15 % of the
-    single-device route at 8192^3 (best of three each)."""
-    import time
-    from test_lu_config_gpu import env
-    n = 8192
-    a = eigen_amd.fill_uniform_host(np.float64, n, n, 1)
-    b = eigen_amd.fill_uniform_host(np.float64, n, n, 2)
-    c0 = eigen_amd.fill_uniform_host(np.float64, n, n, 3)
-
-    def best(knobs):
-        out, t = None, float("inf")
-        with env(**knobs):
-            for _ in range(3):
-                c = c0.copy(order="F")
-                t0 = time.perf_counter()
-                eigen_amd.f77_gemm("N", "N", n, n, n, 1.0, a, n, b, n, 1.0, c, n)
-                t = min(t, time.perf_counter() - t0)
-                out = c
-        return out, t
-
-    c_one, t_one = best(dict(EIGAMD_MULTI_GPU="0"))
-    c_grid, t_grid = best(dict(EIGAMD_MULTI_GPU_VIRTUAL=4))
-    print(f"dgemm_ 8192^3 from host memory: one device {t_one * 1e3:.1f} ms, 2x2 ranks on the same device {t_grid * 1e3:.1f} ms")
-    rows = np.array([0, 1, 2047, 2048, 4100, 8191])
-    gauge = np.abs(a[rows]) @ np.abs(b) + np.abs(c0[rows])
-    assert (np.abs(c_grid[rows] - c_one[rows]) / (ol.EPS[1] * gauge)).max() < RATIO_LIMIT
-    assert t_grid <= 1.15 * t_one, (t_grid, t_one)

@@ -1,0 +1,61 @@
+"""The host route over a grid of devices against the single-device host route, timed in a process of its own.
+
+Four ranks on the one device share its host link, so what the grid's host route can gain or lose against the
+single-device route is overlap alone: operands uploaded in the order the reduction consumes them, the products
+underneath the later uploads, C back as soon as the last product has run (blas/level3_impl.h:12-76 is one call either
+way; the reference hides its split over the cores the same way, Parallelizer.h:101-176).  Within 15 % at 8192^3, best of
+five each.  A fresh process because that is what a caller's process looks like: inside the test session dozens of
+streams of earlier tests (the LU's compute-unit-masked ones among them) share the process's few hardware queues with
+the grid's and take the overlap away (63 ms against 45 there; 46.6 against 44 alone).  Collected late for the same
+reason a timing belongs at the end: a slow box must not hide the parity tests behind it."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SCRIPT = r"""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+import eigen_amd
+import oracle_lib as ol
+n = 8192
+a = eigen_amd.fill_uniform_host(np.float64, n, n, 1)
+b = eigen_amd.fill_uniform_host(np.float64, n, n, 2)
+c0 = eigen_amd.fill_uniform_host(np.float64, n, n, 3)
+def once(knobs):
+    for k in ("EIGAMD_MULTI_GPU", "EIGAMD_MULTI_GPU_VIRTUAL"):
+        os.environ.pop(k, None)
+    os.environ.update(knobs)
+    c = c0.copy(order="F")
+    t0 = time.perf_counter()
+    eigen_amd.f77_gemm("N", "N", n, n, n, 1.0, a, n, b, n, 1.0, c, n)
+    return c, time.perf_counter() - t0
+t_one = t_grid = float("inf")
+for _ in range(5):   # the two routes take turns, so that whatever the box does in between hits both
+    c_one, t = once({"EIGAMD_MULTI_GPU": "0"})
+    t_one = min(t_one, t)
+    c_grid, t = once({"EIGAMD_MULTI_GPU_VIRTUAL": "4"})
+    t_grid = min(t_grid, t)
+rows = np.array([0, 1, 2047, 2048, 4100, 8191])
+gauge = np.abs(a[rows]) @ np.abs(b) + np.abs(c0[rows])
+ratio = float((np.abs(c_grid[rows] - c_one[rows]) / (ol.EPS[1] * gauge)).max())
+print("RESULT " + json.dumps({"t_one": t_one, "t_grid": t_grid, "ratio": ratio}), flush=True)
+"""
+
+
+def test_host_route_over_a_grid_overlaps_its_copies_with_its_products():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("EIGAMD_")}
+    run = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}\n" + SCRIPT], capture_output=True, text=True, timeout=280, env=env)
+    assert run.returncode == 0, run.stderr[-2000:]
+    line = [l for l in run.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    r = json.loads(line[len("RESULT "):])
+    print(f"dgemm_ 8192^3 from host memory: one device {r['t_one'] * 1e3:.1f} ms, 2x2 ranks on the same device {r['t_grid'] * 1e3:.1f} ms")
+    assert r["ratio"] < 16.0
+    assert r["t_grid"] <= 1.15 * r["t_one"], r
