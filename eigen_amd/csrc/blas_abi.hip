@@ -1151,7 +1151,7 @@ int eigamd_getrf_dev_async(int dtype, int64_t m, int64_t n, void* d_a, int64_t l
 
 int eigamd_laswp_dev(int dtype, void* d_a, int64_t lda, int64_t ncols, const int* d_transp, int k0, int k1,
                      void* stream) {
-  if ((dtype != F32 && dtype != F64) || lda < 1 || ncols < 0 || k0 < 0 || k1 < k0)
+  if (dtype < 0 || dtype > 3 || lda < 1 || ncols < 0 || k0 < 0 || k1 < k0)
     return fail(EIGAMD_ERR_ARG, "invalid laswp arguments");
   if (ncols == 0 || k1 == k0) return EIGAMD_OK;
   int rc = ensure_device();
@@ -1162,8 +1162,7 @@ int eigamd_laswp_dev(int dtype, void* d_a, int64_t lda, int64_t ncols, const int
 
 int eigamd_trsm_llnu_dev(int dtype, int64_t m, int64_t n, const void* d_l, int64_t ldl, void* d_b, int64_t ldb,
                          void* stream) {
-  if ((dtype != F32 && dtype != F64) || m < 0 || n < 0 || ldl < std::max<int64_t>(1, m) ||
-      ldb < std::max<int64_t>(1, m))
+  if (dtype < 0 || dtype > 3 || m < 0 || n < 0 || ldl < std::max<int64_t>(1, m) || ldb < std::max<int64_t>(1, m))
     return fail(EIGAMD_ERR_ARG, "invalid trsm arguments");
   if (m == 0 || n == 0) return EIGAMD_OK;
   int rc = ensure_device();

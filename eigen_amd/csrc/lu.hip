@@ -427,7 +427,10 @@ template <typename T> struct RowopsShared {
   int slot[kMaxBase];   // where row p[i] lives in rows
   int last;
 };
-template <typename T, int GROUP = EIGAMD_LU_RANK_GROUP>
+// EARLY (the stand-alone launch, which stands between two base cases): a thread's own row of L and its first group of C
+// are asked for at the very start, so that they travel while the special rows are read and solved -- two dependent trips
+// to memory instead of three.  (Not where the block rides in a base case's kernel: the registers are that kernel's.)
+template <typename T, int GROUP = EIGAMD_LU_RANK_GROUP, bool EARLY = false>
 __device__ __forceinline__ void rowops_rank_update_block(const RowopsArgs<T> args, const int b, RowopsShared<T>& sh) {
   T* __restrict__ base = args.base;
   const int64_t ld = args.ld;
@@ -441,6 +444,20 @@ __device__ __forceinline__ void rowops_rank_update_block(const RowopsArgs<T> arg
   auto& s_slot = sh.slot;
   int& s_last = sh.last;
   const int t = threadIdx.x;
+  T a_early[EARLY ? kMaxBase : 1], c_early[EARLY ? GROUP : 1];
+  if constexpr (EARLY) {
+    if (b < nrb * ncb) {
+      const int rb_ = b % nrb, cb_ = b / nrb;
+      const int lr_ = rb_ * 256 + t, nc_ = min(kRankCols, nright - cb_ * kRankCols);
+      const bool live = lr_ < trows;   // (a special row's loads are harmless: it is skipped below)
+      const T* Lr = base + (k0 + jb + lr_) + (int64_t)cL * ld;
+      const T* Cr_ = base + (k0 + jb + lr_) + (int64_t)(cR + cb_ * kRankCols) * ld;
+#pragma unroll
+      for (int k = 0; k < kMaxBase; ++k) a_early[k] = (live && k < jb) ? Lr[(int64_t)k * ld] : (T)0;
+#pragma unroll
+      for (int u = 0; u < GROUP; ++u) c_early[u] = (live && u < nc_) ? Cr_[(int64_t)u * ld] : (T)0;
+    }
+  }
   if (t < kMaxBase) s_p[t] = t < jb ? transp[k0 + t] : -1;
   for (int i = t; i < jb * jb; i += 256) s_l[(i % jb) + (i / jb) * kMaxBase] = base[(k0 + i % jb) + (int64_t)(cL + i / jb) * ld];
   __syncthreads();
@@ -530,14 +547,20 @@ __device__ __forceinline__ void rowops_rank_update_block(const RowopsArgs<T> arg
   if (plain) {
     T a[kMaxBase];
 #pragma unroll
-    for (int k = 0; k < kMaxBase; ++k) a[k] = k < jb ? base[r + (int64_t)(cL + k) * ld] : (T)0;
+    for (int k = 0; k < kMaxBase; ++k) {
+      if constexpr (EARLY) a[k] = a_early[k];
+      else a[k] = k < jb ? base[r + (int64_t)(cL + k) * ld] : (T)0;
+    }
     T* Cr = colsR + r;
     int j0 = 0;
     constexpr int kGroup = GROUP;   // (8 where the block shares a base case's kernel and its register budget)
     for (; j0 + kGroup <= nc; j0 += kGroup) {
       T c[kGroup];
 #pragma unroll
-      for (int u = 0; u < kGroup; ++u) c[u] = Cr[(int64_t)(j0 + u) * ld];
+      for (int u = 0; u < kGroup; ++u) {
+        if (EARLY && j0 == 0) c[u] = c_early[u];
+        else c[u] = Cr[(int64_t)(j0 + u) * ld];
+      }
 #pragma unroll
       for (int u = 0; u < kGroup; ++u) {
         T acc = (T)0;
@@ -1168,7 +1191,7 @@ __global__ void __launch_bounds__(256) lu_rank_update(const T* __restrict__ A, c
 template <typename T>
 __global__ void __launch_bounds__(256) lu_rowops_rank_update(RowopsArgs<T> args) {
   __shared__ RowopsShared<T> sh;
-  rowops_rank_update_block<T>(args, (int)blockIdx.x, sh);
+  rowops_rank_update_block<T, EIGAMD_LU_RANK_GROUP, sizeof(Real<T>) == sizeof(T)>(args, (int)blockIdx.x, sh);   // (early loads: real scalars, register budget)
 }
 
 // ---- many transpositions at once ----------------------------------------------------
@@ -2575,7 +2598,7 @@ hipError_t getrf_device(int kind, int64_t m, int64_t n, void* A, int64_t ld, int
 
 hipError_t laswp_device(int kind, void* A, int64_t ld, int64_t ncols, const int* d_transp, int k0, int k1,
                         hipStream_t s) {
-  if (kind != F64 && kind != F32) return hipErrorInvalidValue;
+  if (kind < 0 || kind > 3) return hipErrorInvalidValue;
   // The plan scratch is shared by all callers: a use waits for the previous one to finish.
   LuScratch& sc = scratch();
   std::lock_guard<std::mutex> lock(sc.mu);
@@ -2586,8 +2609,13 @@ hipError_t laswp_device(int kind, void* A, int64_t ld, int64_t ncols, const int*
     LU_TRY(hipStreamWaitEvent(s, sc.pub_plan_done, 0));
   }
   SwapPlan* plan = static_cast<SwapPlan*>(sc.pub_plan);
-  hipError_t e = kind == F64 ? laswp<double>(static_cast<double*>(A), ld, ncols, d_transp, k0, k1, plan, s)
-                             : laswp<float>(static_cast<float*>(A), ld, ncols, d_transp, k0, k1, plan, s);
+  hipError_t e = hipSuccess;
+  switch (kind) {
+    case F64: e = laswp<double>(static_cast<double*>(A), ld, ncols, d_transp, k0, k1, plan, s); break;
+    case F32: e = laswp<float>(static_cast<float*>(A), ld, ncols, d_transp, k0, k1, plan, s); break;
+    case C64: e = laswp<Cx<double>>(static_cast<Cx<double>*>(A), ld, ncols, d_transp, k0, k1, plan, s); break;
+    default:  e = laswp<Cx<float>>(static_cast<Cx<float>*>(A), ld, ncols, d_transp, k0, k1, plan, s); break;
+  }
   LU_TRY(e);
   return hipEventRecord(sc.pub_plan_done, s);
 }
@@ -2598,6 +2626,10 @@ hipError_t trsm_llnu_device(int kind, int64_t bs, int64_t ncols, const void* L, 
     return trsm_unit_lower2<double>(static_cast<const double*>(L), ldl, static_cast<double*>(B), ldb, bs, ncols, s);
   if (kind == F32)
     return trsm_unit_lower2<float>(static_cast<const float*>(L), ldl, static_cast<float*>(B), ldb, bs, ncols, s);
+  if (kind == C64)
+    return trsm_unit_lower2<Cx<double>>(static_cast<const Cx<double>*>(L), ldl, static_cast<Cx<double>*>(B), ldb, bs, ncols, s);
+  if (kind == C32)
+    return trsm_unit_lower2<Cx<float>>(static_cast<const Cx<float>*>(L), ldl, static_cast<Cx<float>*>(B), ldb, bs, ncols, s);
   return hipErrorInvalidValue;
 }
 
@@ -2652,24 +2684,6 @@ hipError_t permute_rows(T* B, int64_t ldb, int64_t ncols, const int* transp, int
 }
 
 }  // namespace
-
-// laswp_device for the complex kinds: the transpositions [k0, k1) in order, kPlanSpan at a time as one permutation each.
-hipError_t laswp_device_complex(int kind, void* A, int64_t ld, int64_t ncols, const int* d_transp, int k0, int k1, hipStream_t s) {
-  if (kind != C32 && kind != C64) return hipErrorInvalidValue;
-  if (ncols <= 0 || k1 <= k0) return hipSuccess;
-  LuScratch& sc = scratch();
-  std::lock_guard<std::mutex> lock(sc.mu);
-  if (!sc.pub_plan) {
-    LU_TRY(hipMalloc(&sc.pub_plan, sizeof(SwapPlan)));
-    LU_TRY(hipEventCreateWithFlags(&sc.pub_plan_done, hipEventDisableTiming));
-  } else {
-    LU_TRY(hipStreamWaitEvent(s, sc.pub_plan_done, 0));
-  }
-  SwapPlan* plan = static_cast<SwapPlan*>(sc.pub_plan);
-  LU_TRY(kind == C32 ? permute_rows<Pair32>(static_cast<Pair32*>(A), ld, ncols, d_transp, k1, false, plan, s, k0)
-                     : permute_rows<Pair64>(static_cast<Pair64*>(A), ld, ncols, d_transp, k1, false, plan, s, k0));
-  return hipEventRecord(sc.pub_plan_done, s);
-}
 
 hipError_t getrs_device(int kind, int op, int64_t n, int64_t nrhs, const void* LU, int64_t ldlu, const int* d_transp, void* B,
                         int64_t ldb, hipStream_t s) {

@@ -26,15 +26,11 @@ hipError_t getrf_device(int kind, int64_t m, int64_t n, void* A, int64_t ld, int
 // (One driver for the four kinds: the complex ones are the same kernels over a (re, im) scalar.)
 
 // Row transpositions i <-> d_transp[i], i in [k0, k1), on ncols columns starting at A
-// (row indices are rows of A).
+// (row indices are rows of A).  Any kind.
 hipError_t laswp_device(int kind, void* A, int64_t ld, int64_t ncols, const int* d_transp, int k0, int k1,
                         hipStream_t s);
 
-// The same for the complex kinds (C32, C64).
-hipError_t laswp_device_complex(int kind, void* A, int64_t ld, int64_t ncols, const int* d_transp, int k0, int k1,
-                                hipStream_t s);
-
-// B (bs x ncols) <- L^-1 B, L the unit lower triangle of a bs x bs block.
+// B (bs x ncols) <- L^-1 B, L the unit lower triangle of a bs x bs block.  Any kind.
 hipError_t trsm_llnu_device(int kind, int64_t bs, int64_t ncols, const void* L, int64_t ldl, void* B, int64_t ldb,
                             hipStream_t s);
 

@@ -244,7 +244,7 @@ int eigamd_getrf_dev_async(int dtype, int64_t m, int64_t n, void* d_a, int64_t l
  * PartialPivLU.h:479-489 -- rows i and d_transp[i] of `ncols` columns starting at d_a
  * are exchanged for i = k0 .. k1-1, in order -- and A12 = A11^-1 A12 with A11 unit
  * lower triangular (PartialPivLU.h:492), i.e. ?trsm_("L","L","N","U", m, n, 1, ...) of
- * blas/level3_impl.h:78-178 restricted to that one form. */
+ * blas/level3_impl.h:78-178 restricted to that one form.  Any of the four kinds. */
 int eigamd_laswp_dev(int dtype, void* d_a, int64_t lda, int64_t ncols, const int* d_transp, int k0, int k1,
                      void* stream);
 int eigamd_trsm_llnu_dev(int dtype, int64_t m, int64_t n, const void* d_l, int64_t ldl, void* d_b, int64_t ldb,

@@ -89,7 +89,7 @@ def test_pgemm_pull_transport_between_processes(world, kind, n, nb):
     mp.spawn(_worker, args=(world, _free_port(), kind, n, nb, "ipc"), nprocs=world, join=True)
 
 
-def _lu_worker(rank, world, port, n, transport=None):
+def _lu_worker(rank, world, port, n, transport=None, kind=1):
     import faulthandler
     import sys
     faulthandler.dump_traceback_later(90, exit=True)
@@ -105,8 +105,9 @@ def _lu_worker(rank, world, port, n, transport=None):
     torch.cuda.set_stream(torch.cuda.Stream())   # not the legacy default stream
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        A = ColCyclicMatrix(n, lu_block_size(n), eigen_amd.F64).fill_uniform(77)
-        full = rng_np.matrix(np.float64, 77, n, n)
+        dt = [np.float32, np.float64, np.complex64, np.complex128][kind]
+        A = ColCyclicMatrix(n, lu_block_size(n), kind).fill_uniform(77)
+        full = rng_np.matrix(dt, 77, n, n)
         assert np.array_equal(A.local.to_numpy(), full[:, A.global_cols()])
         ops = DeviceOps
         if os.environ.get("EIGAMD_TEST_VERBOSE"):
@@ -136,12 +137,12 @@ def _lu_worker(rank, world, port, n, transport=None):
         ref_full = torch.from_numpy(ref_np)
         ref = ref_full.numpy()[:, A.global_cols()]
         got = A.local.to_numpy()
-        assert np.abs(got - ref).max() <= 64 * np.finfo(np.float64).eps * n * np.abs(ref).max(), rank
+        assert np.abs(got - ref).max() <= 64 * np.finfo(dt).eps * n * np.abs(ref).max(), rank
         from eigen_amd import lu as ealu
         one = np.asfortranarray(full.copy())
         t2, nb2, fz2 = ealu.blocked_lu(one)
         assert np.array_equal(t2, t1) and nb2 == nb1 and fz2 == -1
-        assert np.abs(got - one[:, A.global_cols()]).max() <= 64 * np.finfo(np.float64).eps * n * np.abs(ref).max(), rank
+        assert np.abs(got - one[:, A.global_cols()]).max() <= 64 * np.finfo(dt).eps * n * np.abs(ref).max(), rank
     finally:
         dist.destroy_process_group()
 
@@ -156,3 +157,9 @@ def test_pgetrf_real_device_steps(world):
 def test_pgetrf_pull_transport_between_processes(world, n):
     """The same with every panel copied out of its owner's HBM by the receivers (inter-process memory handles)."""
     mp.spawn(_lu_worker, args=(world, _free_port(), n, "ipc"), nprocs=world, join=True)
+
+
+def test_pgetrf_complex_between_processes():
+    """The distributed factorisation for a complex kind (the reference binds its blocked_lu for all four,
+    PartialPivLU_LAPACKE.h:74-79): panels pulled between three processes, pivots identical to the oracle's."""
+    mp.spawn(_lu_worker, args=(3, _free_port(), 1100, "ipc", 3), nprocs=3, join=True)
