@@ -28,9 +28,17 @@ struct GemmCall {
   // place of splitk_workspace(): the launch path then allocates nothing.
   void* partials = nullptr;
   size_t partials_bytes = 0;
+  bool partials_keep_helpers = false;  // with `partials`: the edge strips may still run on the library's helper streams
   // Real kinds, beta == 1: accumulate into C with memory-side atomic adds (GemmParams::atomic_c).  C must
   // be ordinary device memory (hipMalloc); ignored for the complex kinds and for other beta.
   bool atomic_c = false;
+  // beta == 0 only.  When the launcher cuts the whole reduction into pieces, the pass that adds the pieces up writes
+  // alpha * sum to split_dest (leading dimension split_ldd) instead of C and sets *split_dest_used; split_dest may be
+  // one of the operands -- every read of A and B is over before that pass starts.  Otherwise the product goes to C as
+  // usual and the flag stays as it was.  (The triangular solves' leaves: B_j <- inv_j * B_j without a copy.)
+  void* split_dest = nullptr;
+  int64_t split_ldd = 0;
+  bool* split_dest_used = nullptr;
 };
 
 // Block-to-tile mapping knobs; the defaults are what the shipped library uses, the
@@ -276,7 +284,11 @@ static hipError_t launch_whole(const GemmCall& c, hipStream_t stream) {
     int slot = -1;
     if (void* partials = c.partials ? (bytes <= c.partials_bytes ? c.partials : nullptr) : splitk_acquire(stream, bytes, &slot)) {
       hipError_t e = launch_region<KIND, AK, BKC, GUARD>(c, 0, 0, c.m, c.n, stream, splits, k_chunk, partials);
-      if (e == hipSuccess) e = reduce_partials<KIND>(c, 0, 0, c.m, c.n, splits, partials, stream);
+      const bool redirect = c.split_dest != nullptr && c.beta[0] == 0.0 && c.beta[1] == 0.0;
+      GemmCall cr = c;
+      if (redirect) { cr.C = c.split_dest; cr.ldc = c.split_ldd; }
+      if (e == hipSuccess) e = reduce_partials<KIND>(cr, 0, 0, c.m, c.n, splits, partials, stream);
+      if (e == hipSuccess && redirect && c.split_dest_used) *c.split_dest_used = true;
       if (slot >= 0) splitk_release(slot, stream);
       return e;
     }
@@ -390,7 +402,7 @@ static hipError_t launch_layout(const GemmCall& c, hipStream_t stream) {
     hipStream_t sa = stream, sb = stream;
     // The strips write parts of C disjoint from the interior's and from each other's, and read
     // A and B only: the three launches may run side by side.
-    const bool fork = (bottom || right) && !c.serial_edges && !c.partials;  // (helper streams are created on first use)
+    const bool fork = (bottom || right) && !c.serial_edges && (!c.partials || c.partials_keep_helpers);  // (helper streams are created on first use)
     if (fork) {
       e = edge_streams_fork(stream, &sa, &sb);
       if (e != hipSuccess) return e;

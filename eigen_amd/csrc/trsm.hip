@@ -90,9 +90,21 @@ template <> struct One<Cplx<double>> { static __device__ Cplx<double> v() { retu
 // a lower one.  grid = (kNB / kInvCols, number of blocks); a workgroup owns 32 columns of
 // one inverse in LDS and walks down the rows 32 at a time: first the part of the inner
 // products that needs finished rows only, then the 32 x 32 triangle on the diagonal.
+// It also notes, per block, max|inv(T_b)| and max|T_b| over what it wrote and read (gmax[2 b], gmax[2 b + 1]: the bit
+// patterns of non-negative doubles order like the numbers, NaN above infinity, so an integer atomicMax folds them; the
+// words are zero on entry), which is all trtri_decide needs.
+__device__ __forceinline__ void note_max(unsigned long long* word, double v) {
+  unsigned long long b = (unsigned long long)__double_as_longlong(fabs(v));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_down(b, off, 64);
+    b = o > b ? o : b;
+  }
+  if ((threadIdx.x & 63) == 0 && b != 0) atomicMax(word, b);
+}
 template <typename T, int NB>
 __global__ void __launch_bounds__(256) trtri_blocks(const T* __restrict__ A, int64_t lda, int na, int upper, int unit,
-                                                    T* __restrict__ X) {
+                                                    T* __restrict__ X, unsigned long long* __restrict__ gmax) {
   constexpr int kNB = NB;   // block extent of this instantiation
   __shared__ T s_x[kInvCols][kNB + 1];
   __shared__ T s_acc[kInvCols][kInvCols + 1];
@@ -153,56 +165,41 @@ __global__ void __launch_bounds__(256) trtri_blocks(const T* __restrict__ A, int
     __syncthreads();
   }
   // full kNB x kNB image, zeros outside the bs x bs triangle
+  double mx = 0.0, ma = unit ? 1.0 : 0.0;
   for (int idx = threadIdx.x; idx < kInvCols * kNB; idx += 256) {
     const int c = idx / kNB, i = idx % kNB;
     const int g = first + c;
     const T v = (g < bs && i < bs) ? s_x[c][i] : zero_of<T>();
     if (upper) Xb[g + (int64_t)i * kNB] = v;
     else Xb[i + (int64_t)g * kNB] = v;
+    const double vm = mag(v);
+    mx = (vm > mx || vm != vm) ? vm : mx;
+    if (g < bs && i < bs && (i > g || (i == g && !unit))) {   // the stored triangle, this workgroup's columns
+      const double a = mag(i == g ? Ab[g + (int64_t)g * lda] : at(i, g));
+      ma = (a > ma || a != a) ? a : ma;
+    }
   }
+  note_max(gmax + 2 * blockIdx.y, mx);
+  note_max(gmax + 2 * blockIdx.y + 1, ma);
 }
 
-
-// max over a workgroup of 256 threads; NaN wins (a block with a NaN must not pass as small).
-__device__ __forceinline__ double block_max_nan(double v) {
-  __shared__ double s_m[4];
-  __syncthreads();
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const double o = __shfl_down(v, off, 64);
-    v = (o > v || o != o) ? o : v;
-  }
-  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = v;
-  __syncthreads();
-  double r = s_m[0];
-  for (int w = 1; w < 4; ++w) r = (s_m[w] > r || s_m[w] != s_m[w]) ? s_m[w] : r;
-  return r;
-}
 
 // After trtri_blocks: flags[b] = 1 when max|inv(T_b)| * max|T_b| exceeds `limit` or is not finite;
 // the inverse of such a block is replaced by the identity (the block is solved by substitution).
 // grid = number of blocks, 256 threads.
 template <typename T, int NB>
-__global__ void __launch_bounds__(256) trtri_decide(const T* __restrict__ A, int64_t lda, int na, int upper, int unit,
-                                                    T* __restrict__ X, double limit, int* __restrict__ flags) {
-  const int b0 = blockIdx.x * NB;
-  const int bs = min(NB, na - b0);
-  const T* Ab = A + b0 + (int64_t)b0 * lda;
+__global__ void __launch_bounds__(256) trtri_decide(T* __restrict__ X, double limit, const unsigned long long* __restrict__ gmax,
+                                                    int* __restrict__ flags) {
   T* Xb = X + (int64_t)blockIdx.x * NB * NB;
-  double mx = 0.0, ma = unit ? 1.0 : 0.0;
-  for (int idx = threadIdx.x; idx < NB * NB; idx += 256) {
-    const double v = mag(Xb[idx]);
-    mx = (v > mx || v != v) ? v : mx;
-    const int i = idx % NB, k = idx / NB;  // stored triangle of the block: i >= k of the lower form
-    if (i < bs && k < bs && (i > k || (i == k && !unit))) {
-      const double a = mag(upper ? Ab[k + (int64_t)i * lda] : Ab[i + (int64_t)k * lda]);
-      ma = (a > ma || a != a) ? a : ma;
-    }
+  __shared__ int s_subst;
+  if (threadIdx.x == 0) {
+    const double mx = __longlong_as_double((long long)gmax[2 * blockIdx.x]);
+    const double ma = __longlong_as_double((long long)gmax[2 * blockIdx.x + 1]);   // (at least 1 for a unit diagonal)
+    s_subst = !(mx * ma <= limit);
+    flags[blockIdx.x] = s_subst;
   }
-  mx = block_max_nan(mx);
-  ma = block_max_nan(ma);
-  const bool subst = !(mx * ma <= limit);
-  if (threadIdx.x == 0) flags[blockIdx.x] = subst ? 1 : 0;
+  __syncthreads();
+  const bool subst = s_subst != 0;
   if (subst)
     for (int idx = threadIdx.x; idx < NB * NB; idx += 256) Xb[idx] = (idx % NB == idx / NB) ? One<T>::v() : zero_of<T>();
 }
@@ -279,7 +276,8 @@ inline double growth_limit() {
 }
 
 hipError_t gemm(int kind, int opa, int opb, int64_t m, int64_t n, int64_t k, double alpha, const void* A, int64_t lda,
-                const void* B, int64_t ldb, double beta, void* C, int64_t ldc, hipStream_t s) {
+                const void* B, int64_t ldb, double beta, void* C, int64_t ldc, hipStream_t s, void* partials, size_t partials_bytes,
+                void* split_dest = nullptr, int64_t split_ldd = 0, bool* split_dest_used = nullptr) {
   if (m <= 0 || n <= 0) return hipSuccess;
   GemmCall c;
   c.kind = kind;
@@ -290,6 +288,8 @@ hipError_t gemm(int kind, int opa, int opb, int64_t m, int64_t n, int64_t k, dou
   c.A = A; c.lda = lda;
   c.B = B; c.ldb = ldb;
   c.C = C; c.ldc = ldc;
+  c.split_dest = split_dest; c.split_ldd = split_ldd; c.split_dest_used = split_dest_used;
+  c.partials = partials; c.partials_bytes = partials_bytes; c.partials_keep_helpers = true;
   switch (kind) {
     case F32: return launch_gemm_f32(c, s);
     case F64: return launch_gemm_f64(c, s);
@@ -344,7 +344,8 @@ hipError_t trsm_device(int kind, bool left, bool upper, int op, bool unit, int64
   InvScratch& sc = inv_scratch();
   std::lock_guard<std::mutex> lock(sc.mu);
   const size_t inv_bytes = (size_t)nblk * kNB * kNB * es;
-  const size_t flag_bytes = ((size_t)nblk * sizeof(int) + 255) / 256 * 256;
+  const size_t max_bytes = ((size_t)nblk * 2 * sizeof(unsigned long long) + 255) / 256 * 256;   // max|inv(T_b)|, max|T_b|
+  const size_t flag_bytes = ((size_t)nblk * sizeof(int) + 255) / 256 * 256 + max_bytes;
   const size_t leaf_bytes = leaf_copy ? (size_t)(left ? n : m) * kNB * es : 0;   // one leaf's result
   const size_t need = inv_bytes + flag_bytes + leaf_bytes;
   if (!sc.done) TR_TRY(hipEventCreateWithFlags(&sc.done, hipEventDisableTiming));
@@ -362,63 +363,58 @@ hipError_t trsm_device(int kind, bool left, bool upper, int op, bool unit, int64
   }
   const dim3 grid((unsigned)(kNB / kInvCols), (unsigned)nblk);
   const int up = upper ? 1 : 0, un = unit ? 1 : 0;
+  int* flags = reinterpret_cast<int*>(static_cast<char*>(sc.buf) + inv_bytes);
+  unsigned long long* gmax = reinterpret_cast<unsigned long long*>(static_cast<char*>(sc.buf) + inv_bytes + flag_bytes - max_bytes);
+  TR_TRY(hipMemsetAsync(gmax, 0, max_bytes, s));
   switch (kind) {
     case F32:
       if (kNB == kLargeNB)
         hipLaunchKernelGGL((trtri_blocks<float, kLargeNB>), grid, dim3(256), 0, s, static_cast<const float*>(A), lda, (int)na, up,
-                           un, static_cast<float*>(sc.buf));
+                           un, static_cast<float*>(sc.buf), gmax);
       else
         hipLaunchKernelGGL((trtri_blocks<float, kSmallNB>), grid, dim3(256), 0, s, static_cast<const float*>(A), lda, (int)na, up,
-                           un, static_cast<float*>(sc.buf));
+                           un, static_cast<float*>(sc.buf), gmax);
       break;
     case F64:
       if (kNB == kLargeNB)
         hipLaunchKernelGGL((trtri_blocks<double, kLargeNB>), grid, dim3(256), 0, s, static_cast<const double*>(A), lda, (int)na,
-                           up, un, static_cast<double*>(sc.buf));
+                           up, un, static_cast<double*>(sc.buf), gmax);
       else
         hipLaunchKernelGGL((trtri_blocks<double, kSmallNB>), grid, dim3(256), 0, s, static_cast<const double*>(A), lda, (int)na,
-                           up, un, static_cast<double*>(sc.buf));
+                           up, un, static_cast<double*>(sc.buf), gmax);
       break;
     case C32:
       hipLaunchKernelGGL((trtri_blocks<Cplx<float>, kSmallNB>), grid, dim3(256), 0, s, static_cast<const Cplx<float>*>(A), lda,
-                         (int)na, up, un, static_cast<Cplx<float>*>(sc.buf));
+                         (int)na, up, un, static_cast<Cplx<float>*>(sc.buf), gmax);
       break;
     default:
       hipLaunchKernelGGL((trtri_blocks<Cplx<double>, kSmallNB>), grid, dim3(256), 0, s, static_cast<const Cplx<double>*>(A), lda,
-                         (int)na, up, un, static_cast<Cplx<double>*>(sc.buf));
+                         (int)na, up, un, static_cast<Cplx<double>*>(sc.buf), gmax);
       break;
   }
   TR_TRY(hipGetLastError());
-  int* flags = reinterpret_cast<int*>(static_cast<char*>(sc.buf) + inv_bytes);
   const double limit = growth_limit();
+#define EIGAMD_DECIDE(TYPE, NBV) \
+  hipLaunchKernelGGL((trtri_decide<TYPE, NBV>), dim3((unsigned)nblk), dim3(256), 0, s, static_cast<TYPE*>(sc.buf), limit, gmax, flags)
   switch (kind) {
-    case F32:
-      if (kNB == kLargeNB)
-        hipLaunchKernelGGL((trtri_decide<float, kLargeNB>), dim3((unsigned)nblk), dim3(256), 0, s, static_cast<const float*>(A), lda,
-                           (int)na, up, un, static_cast<float*>(sc.buf), limit, flags);
-      else
-        hipLaunchKernelGGL((trtri_decide<float, kSmallNB>), dim3((unsigned)nblk), dim3(256), 0, s, static_cast<const float*>(A), lda,
-                           (int)na, up, un, static_cast<float*>(sc.buf), limit, flags);
-      break;
-    case F64:
-      if (kNB == kLargeNB)
-        hipLaunchKernelGGL((trtri_decide<double, kLargeNB>), dim3((unsigned)nblk), dim3(256), 0, s, static_cast<const double*>(A), lda,
-                           (int)na, up, un, static_cast<double*>(sc.buf), limit, flags);
-      else
-        hipLaunchKernelGGL((trtri_decide<double, kSmallNB>), dim3((unsigned)nblk), dim3(256), 0, s, static_cast<const double*>(A), lda,
-                           (int)na, up, un, static_cast<double*>(sc.buf), limit, flags);
-      break;
-    case C32:
-      hipLaunchKernelGGL((trtri_decide<Cplx<float>, kSmallNB>), dim3((unsigned)nblk), dim3(256), 0, s, static_cast<const Cplx<float>*>(A),
-                         lda, (int)na, up, un, static_cast<Cplx<float>*>(sc.buf), limit, flags);
-      break;
-    default:
-      hipLaunchKernelGGL((trtri_decide<Cplx<double>, kSmallNB>), dim3((unsigned)nblk), dim3(256), 0, s,
-                         static_cast<const Cplx<double>*>(A), lda, (int)na, up, un, static_cast<Cplx<double>*>(sc.buf), limit, flags);
-      break;
+    case F32: if (kNB == kLargeNB) EIGAMD_DECIDE(float, kLargeNB); else EIGAMD_DECIDE(float, kSmallNB); break;
+    case F64: if (kNB == kLargeNB) EIGAMD_DECIDE(double, kLargeNB); else EIGAMD_DECIDE(double, kSmallNB); break;
+    case C32: EIGAMD_DECIDE(Cplx<float>, kSmallNB); break;
+    default:  EIGAMD_DECIDE(Cplx<double>, kSmallNB); break;
   }
+#undef EIGAMD_DECIDE
   TR_TRY(hipGetLastError());
   auto inv = [&](int64_t j) { return static_cast<const char*>(sc.buf) + (size_t)j * kNB * kNB * es; };
+  // One buffer for the pieces of every cut reduction of this solve (the solve is a chain of some dozens of products,
+  // most of them of few tiles): taken from the library's pool once and given back at the end, instead of once per
+  // product -- every hand-back records an event, and the marker costs the stream 5 us (dtrsm 4096: 31 of them).
+  int ws_slot = -1;
+  const size_t ws_bytes = std::min<size_t>((size_t)256 << 20, std::max<size_t>((size_t)4 * m * n * es, (size_t)16 * kNB * (left ? n : m) * es));
+  void* ws = splitk_acquire(s, ws_bytes, &ws_slot);   // (null: no buffer to be had; the products then ask for themselves)
+  struct Release {
+    int slot; hipStream_t s;
+    ~Release() { if (slot >= 0) splitk_release(slot, s); }
+  } release_ws{ws_slot, s};
 
   const bool notrans = op == OP_N || op == OP_CONJ;
   const bool eff_lower = (!upper) == notrans;  // op(A) is lower triangular
@@ -457,20 +453,26 @@ hipError_t trsm_device(int kind, bool left, bool upper, int op, bool unit, int64
       const int64_t p0 = j0 * kNB, pb = std::min<int64_t>(kNB, ext - p0);
       TR_TRY(subst(j0, p0, pb));
       if (leaf_copy) {  // the product into the scratch image (any tile may run it), then back
+        // (Where the launcher cuts the leaf's reduction into pieces -- it does for most leaves: few tiles -- the pass
+        // over the pieces writes B_j itself and there is nothing to copy: 16 us less per leaf, copy and the two gaps
+        // around it.)
         char* leaf = static_cast<char*>(sc.buf) + inv_bytes + flag_bytes;
+        bool direct = false;
         if (left) {
-          TR_TRY(gemm(kind, op, OP_N, pb, n, pb, 1.0, inv(j0), kNB, b_at(p0, 0), ldb, 0.0, leaf, pb, s));
+          TR_TRY(gemm(kind, op, OP_N, pb, n, pb, 1.0, inv(j0), kNB, b_at(p0, 0), ldb, 0.0, leaf, pb, s, ws, ws ? ws_bytes : 0, b_at(p0, 0), ldb, &direct));
+          if (direct) return hipSuccess;
           return hipMemcpy2DAsync(b_at(p0, 0), (size_t)ldb * es, leaf, (size_t)pb * es, (size_t)pb * es, (size_t)n,
                                   hipMemcpyDeviceToDevice, s);
         }
-        TR_TRY(gemm(kind, OP_N, op, m, pb, pb, 1.0, b_at(0, p0), ldb, inv(j0), kNB, 0.0, leaf, m, s));
+        TR_TRY(gemm(kind, OP_N, op, m, pb, pb, 1.0, b_at(0, p0), ldb, inv(j0), kNB, 0.0, leaf, m, s, ws, ws ? ws_bytes : 0, b_at(0, p0), ldb, &direct));
+        if (direct) return hipSuccess;
         return hipMemcpy2DAsync(b_at(0, p0), (size_t)ldb * es, leaf, (size_t)m * es, (size_t)m * es, (size_t)pb,
                                 hipMemcpyDeviceToDevice, s);
       }
       if (left)  // B_j <- op(inv_j) * B_j, in place (one tile row)
-        return gemm(kind, op, OP_N, pb, n, pb, 1.0, inv(j0), kNB, b_at(p0, 0), ldb, 0.0, b_at(p0, 0), ldb, s);
+        return gemm(kind, op, OP_N, pb, n, pb, 1.0, inv(j0), kNB, b_at(p0, 0), ldb, 0.0, b_at(p0, 0), ldb, s, ws, ws ? ws_bytes : 0);
       // B_j <- B_j * op(inv_j), in place (one tile column)
-      return gemm(kind, OP_N, op, m, pb, pb, 1.0, b_at(0, p0), ldb, inv(j0), kNB, 0.0, b_at(0, p0), ldb, s);
+      return gemm(kind, OP_N, op, m, pb, pb, 1.0, b_at(0, p0), ldb, inv(j0), kNB, 0.0, b_at(0, p0), ldb, s, ws, ws ? ws_bytes : 0);
     }
     const int64_t jm = j0 + (j1 - j0 + 1) / 2;
     const int64_t lo0 = j0 * kNB, lo1 = jm * kNB, hi1 = std::min<int64_t>(j1 * kNB, ext);
@@ -483,11 +485,11 @@ hipError_t trsm_device(int kind, bool left, bool upper, int op, bool unit, int64
     if (left) {
       // B_q -= op(A)(q, f) * B_f
       const void* Aqf = notrans ? a_at(q0, f0) : a_at(f0, q0);
-      TR_TRY(gemm(kind, op, OP_N, qn, n, fn, -1.0, Aqf, lda, b_at(f0, 0), ldb, 1.0, b_at(q0, 0), ldb, s));
+      TR_TRY(gemm(kind, op, OP_N, qn, n, fn, -1.0, Aqf, lda, b_at(f0, 0), ldb, 1.0, b_at(q0, 0), ldb, s, ws, ws ? ws_bytes : 0));
     } else {
       // B_q -= B_f * op(A)(f, q)
       const void* Afq = notrans ? a_at(f0, q0) : a_at(q0, f0);
-      TR_TRY(gemm(kind, OP_N, op, m, qn, fn, -1.0, b_at(0, f0), ldb, Afq, lda, 1.0, b_at(0, q0), ldb, s));
+      TR_TRY(gemm(kind, OP_N, op, m, qn, fn, -1.0, b_at(0, f0), ldb, Afq, lda, 1.0, b_at(0, q0), ldb, s, ws, ws ? ws_bytes : 0));
     }
     return low_first ? rec.run(jm, j1) : rec.run(j0, jm);
   };
