@@ -736,18 +736,25 @@ hipError_t edge_streams_fork(hipStream_t s, hipStream_t* a, hipStream_t* b) {
 }
 
 namespace {
-// A small pool of buffers per device for the partial products of split reductions.  Each buffer
-// remembers the stream that used it last and an event recorded behind that use.
+// A small pool of buffers per device for the partial products of split reductions.  Each buffer remembers the stream
+// that used it last.  While every stream that asks finds a buffer of its own (at most kSlots streams), a buffer never
+// changes hands and the stream's own order is all the ordering there is to keep: nothing is recorded, nothing waited
+// for (an event recorded behind every use costs the stream a marker, 5 to 6 us between two kernels -- a tenth of a
+// 1024^3 product).  A stream is told from a later one that happens to get the same handle by its id.  The first time a
+// buffer has to change hands the device is brought to rest once, and from then on every use is fenced by an event
+// (recorded at the hand-back, waited for by the next taker), which is always right and was the only mode before.
 struct SplitWorkspaces {
   static constexpr int kSlots = 8;
   std::mutex mu;
   int off = -1;  // -1: environment not read yet
+  bool fenced = false;   // every use is followed by an event (see above)
   uint64_t clock = 0;
   struct Slot {
     hipStream_t stream = nullptr;
+    unsigned long long stream_id = 0;
     void* buf = nullptr;
     size_t bytes = 0;
-    hipEvent_t done = nullptr;   // recorded by splitk_release
+    hipEvent_t done = nullptr;   // recorded by splitk_release (fenced mode)
     bool released = true, used = false;
     uint64_t stamp = 0;
   } slot[kSlots];
@@ -766,28 +773,53 @@ void* splitk_acquire(hipStream_t s, size_t bytes, int* slot_out) {
   if (w.off < 0) {
     const char* e = getenv("EIGAMD_SPLITK");
     w.off = (e && atoi(e) == 0) ? 1 : 0;
+    if (const char* f = getenv("EIGAMD_SPLITK_FENCED")) w.fenced = atoi(f) != 0;   // (measurements: the events from the start)
   }
   if (w.off) return nullptr;
-  // the buffer this stream used last; else the least recently used one that is not in the hands of
-  // a caller right now (between acquire and release)
+  unsigned long long id = 0;
+  if (!w.fenced && hipStreamGetId(s, &id) != hipSuccess) {   // no way to tell streams apart: the events, then
+    (void)hipGetLastError();
+    if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    w.fenced = true;
+  }
   int pick = -1;
-  for (int i = 0; i < SplitWorkspaces::kSlots; ++i)
-    if (w.slot[i].used && w.slot[i].stream == s && w.slot[i].released) { pick = i; break; }
-  if (pick < 0)
-    for (int i = 0; i < SplitWorkspaces::kSlots; ++i)
-      if (w.slot[i].released && (pick < 0 || w.slot[i].stamp < w.slot[pick].stamp)) pick = i;
+  if (!w.fenced) {
+    // this stream's own buffer, else one nobody has used yet
+    for (int i = 0; i < SplitWorkspaces::kSlots && pick < 0; ++i)
+      if (w.slot[i].used && w.slot[i].released && w.slot[i].stream == s && w.slot[i].stream_id == id) pick = i;
+    for (int i = 0; i < SplitWorkspaces::kSlots && pick < 0; ++i)
+      if (!w.slot[i].used) pick = i;
+    if (pick < 0) {
+      // A buffer has to change hands (more streams than buffers, or this stream's buffer is in a caller's hands):
+      // whatever the buffers' last users queued is allowed to finish, once, and the events take over.
+      if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+      w.fenced = true;
+      for (int i = 0; i < SplitWorkspaces::kSlots; ++i) w.slot[i].used = w.slot[i].used && !w.slot[i].released;   // (at rest: no last use to wait for)
+    }
+  }
+  if (w.fenced) {
+    // the buffer this stream used last; else the least recently used one that is not in the hands of
+    // a caller right now (between acquire and release)
+    for (int i = 0; i < SplitWorkspaces::kSlots && pick < 0; ++i)
+      if (w.slot[i].used && w.slot[i].stream == s && w.slot[i].released) pick = i;
+    if (pick < 0)
+      for (int i = 0; i < SplitWorkspaces::kSlots; ++i)
+        if (w.slot[i].released && (pick < 0 || w.slot[i].stamp < w.slot[pick].stamp)) pick = i;
+  }
   if (pick < 0) return nullptr;
   SplitWorkspaces::Slot& t = w.slot[pick];
-  // Behind the buffer's last use.  (Also when the handle is the same: a destroyed stream's handle
-  // value can come back as a new stream; on the same live stream the wait costs nothing.)
-  if (t.used && t.done && hipStreamWaitEvent(s, t.done, 0) != hipSuccess) {
-    (void)hipGetLastError();
-    return nullptr;
-  }
-  if (!t.done && hipEventCreateWithFlags(&t.done, hipEventDisableTiming) != hipSuccess) {
-    (void)hipGetLastError();
-    t.done = nullptr;
-    return nullptr;
+  if (w.fenced) {
+    // Behind the buffer's last use.  (Also when the handle is the same: a destroyed stream's handle
+    // value can come back as a new stream.)
+    if (t.used && t.done && hipStreamWaitEvent(s, t.done, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    if (!t.done && hipEventCreateWithFlags(&t.done, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      t.done = nullptr;
+      return nullptr;
+    }
   }
   if (t.bytes < bytes) {
     // hipFree waits for the device, so nothing queued earlier still reads the old buffer.
@@ -801,7 +833,7 @@ void* splitk_acquire(hipStream_t s, size_t bytes, int* slot_out) {
     }
     t.bytes = want;
   }
-  t.stream = s; t.used = true; t.released = false; t.stamp = ++w.clock;
+  t.stream = s; t.stream_id = id; t.used = true; t.released = false; t.stamp = ++w.clock;
   *slot_out = pick;
   return t.buf;
 }
@@ -811,7 +843,14 @@ void splitk_release(int slot, hipStream_t s) {
   std::lock_guard<std::mutex> lock(w.mu);
   if (slot < 0 || slot >= SplitWorkspaces::kSlots) return;
   SplitWorkspaces::Slot& t = w.slot[slot];
-  if (t.done) (void)hipEventRecord(t.done, s);
+  if (w.fenced) {
+    if (!t.done && hipEventCreateWithFlags(&t.done, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      t.done = nullptr;
+      (void)hipStreamSynchronize(s);   // no event to be had: the use is over before anybody else can take the buffer
+    }
+    if (t.done) (void)hipEventRecord(t.done, s);
+  }
   t.released = true;
 }
 
