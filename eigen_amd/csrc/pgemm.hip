@@ -652,6 +652,7 @@ int eigamd_pgemm_host(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t
     std::vector<int> landed;   // landed[p]: devices whose blocks of panel p (and, with p == 0, of C) are in device memory
     bool issued = false;       // every product has been queued and Rank::done recorded behind the last one
     int rc = EIGAMD_OK;        // first failure of any thread
+    std::string what;          // ... and its text (eigamd_last_error() is per thread: the caller's thread repeats it)
   } sh;
   sh.landed.assign((size_t)npanels, 0);
   char* ah = const_cast<char*>(static_cast<const char*>(a));
@@ -659,7 +660,10 @@ int eigamd_pgemm_host(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t
   char* ch = static_cast<char*>(c);
   auto fail_with = [&](int code) {
     std::lock_guard<std::mutex> l(sh.mu);
-    if (sh.rc == EIGAMD_OK) sh.rc = code;
+    if (sh.rc == EIGAMD_OK) {
+      sh.rc = code;
+      sh.what = eigamd_last_error();
+    }
     sh.cv.notify_all();
   };
   auto device_thread = [&](int dev) {
@@ -720,7 +724,7 @@ int eigamd_pgemm_host(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t
   }
   sh.cv.notify_all();
   for (std::thread& t : threads) t.join();
-  if (rc == EIGAMD_OK) rc = sh.rc;
+  if (rc == EIGAMD_OK && sh.rc != EIGAMD_OK) rc = abi_fail(sh.rc, sh.what);
   if (rc == EIGAMD_OK) rc = eigamd_pgemm_sync(g);
   if (rc != EIGAMD_OK) drop_grid();
   if (trace) fprintf(stderr, "pgemm_host: done at %.2f ms\n", since());
