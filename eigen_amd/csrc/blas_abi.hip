@@ -5,6 +5,8 @@
 // the MFMA kernels; there is no CPU compute path in this library.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -777,7 +779,11 @@ void* splitk_acquire(hipStream_t s, size_t bytes, int* slot_out) {
   }
   if (w.off) return nullptr;
   unsigned long long id = 0;
-  if (!w.fenced && hipStreamGetId(s, &id) != hipSuccess) {   // no way to tell streams apart: the events, then
+  // (hipStreamGetId is looked up at run time: it is younger than the runtime some hosts bring along -- a PyTorch wheel
+  // ships its own libamdhip64 -- and a library that required it would not load there.  Where it is missing: the events.)
+  typedef hipError_t (*StreamIdFn)(hipStream_t, unsigned long long*);
+  static const StreamIdFn stream_id = reinterpret_cast<StreamIdFn>(dlsym(RTLD_DEFAULT, "hipStreamGetId"));
+  if (!w.fenced && (!stream_id || stream_id(s, &id) != hipSuccess)) {   // no way to tell streams apart: the events, then
     (void)hipGetLastError();
     if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     w.fenced = true;

@@ -136,3 +136,15 @@ def test_tile_shapes():
     for kind in range(4):
         bm, bn, bk = _lib.tile_shape(kind)
         assert bm % 32 == 0 and bn % 32 == 0 and bk * np.dtype(ol.DTYPES[kind]).itemsize in (128, 256)
+
+
+def test_library_loads_in_a_process_that_imported_torch_first():
+    """bench.py and the multi-rank drivers import torch before the library, and a PyTorch wheel ships its own HIP
+    runtime, possibly older than the toolkit the library was built with: the library must not require a runtime
+    symbol that runtime lacks (hipStreamGetId, version hip_7.1, did once; it is looked up at run time now)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, "-c", "import torch, sys; sys.path.insert(0, %r); import eigen_amd; print('ok')" % root],
+                         capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and "ok" in run.stdout, run.stderr[-2000:]
