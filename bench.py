@@ -626,6 +626,8 @@ def main():
                 out["extra"].update(lu_measurement(32768))
                 out["extra"].update(lu_sweep_measurements())
                 out["extra"].update(trsm_measurement(16384))
+                out["extra"].update(trsm_measurement(8192))
+                out["extra"].update(trsm_measurement(4096))
                 out["extra"].update(syrk_measurement(16384))
                 out["extra"].update(trmm_measurement(16384))
                 out["extra"].update(mixed_measurement(8192))
