@@ -142,3 +142,20 @@ def test_two_part_launch_sampled(kind, m, n, k, ops):
     scale = np.abs(opmat(ha, opa)).astype(np.float64) @ (np.abs(opmat(hb, opb)).astype(np.float64) @ np.abs(v)) + \
         np.abs(hc).astype(np.float64) @ np.abs(v)
     assert (np.abs(lhs - rhs) <= 64 * ol.EPS[kind] * np.maximum(scale, 1.0) * 4).all()
+
+
+def test_more_streams_than_buffers_for_the_pieces():
+    """Twelve streams multiply at once (the library keeps eight buffers for the pieces of a cut reduction), streams are
+    destroyed and created in between: the buffers change hands, first unfenced, then fenced by events, and every
+    product stays the bits of the same product run alone.  A stand-alone program (tools/splitk_streams_check.hip, built
+    into build/ by __graft_entry__.build()): this process imported PyTorch, whose HIP runtime may lack the stream ids
+    the unfenced mode tells streams apart by."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "splitk_streams_check")
+    if not os.path.exists(exe):
+        pytest.skip("build/splitk_streams_check not built")
+    for env_extra in ({}, {"EIGAMD_SPLITK_FENCED": "1"}):
+        run = subprocess.run([exe, "12", "6", "1024"], capture_output=True, text=True, timeout=200, env={**os.environ, **env_extra})
+        print(run.stdout[-600:])
+        assert run.returncode == 0 and "SPLITK STREAMS CHECK OK" in run.stdout, run.stdout[-2000:] + run.stderr[-2000:]
