@@ -362,3 +362,24 @@ def test_calls_that_do_not_wait_share_the_scratch_in_order():
         a2 = np.asfortranarray(d.as_strided().cpu().numpy())
         assert check_against_oracle(a, a1, t1, a2, transp.cpu().numpy(), exact_pivots=True) is None
         assert nb1 == nb2
+
+
+@pytest.mark.parametrize("kind_name,n,runs", [("f64", 4096, 6), ("c64", 2304, 4), ("f32", 3000, 4)])
+def test_every_run_gives_the_same_bits(kind_name, n, runs):
+    """The factorisation has workgroups that ride in other kernels' launches, arrival counters, memory-side adds and four
+    streams; none of it may make the result depend on timing: transpositions and factors of repeated runs are equal bit for bit."""
+    import torch
+    from eigen_amd.device import DeviceMatrix
+    kind = {"f32": eigen_amd.F32, "f64": eigen_amd.F64, "c64": eigen_amd.C64}[kind_name]
+    a = DeviceMatrix(n, n, kind)
+    first = None
+    for _ in range(runs):
+        a.fill_uniform(77)
+        transp, nb, fz = ealu.getrf_dev(a)
+        torch.cuda.synchronize()
+        lu = a.as_strided()
+        cur = (transp.clone(), (torch.view_as_real(lu) if kind >= 2 else lu).clone(), nb, fz)
+        if first is None:
+            first = cur
+        else:
+            assert torch.equal(cur[0], first[0]) and torch.equal(cur[1], first[1]) and cur[2:] == first[2:]
