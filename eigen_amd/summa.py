@@ -188,7 +188,7 @@ def pgemm(alpha, A, B, beta, C, local_gemm=None, broadcast=None, transport=None,
             local_gemm(alpha, A.local.block(0, 0, A.mloc, 0), B.local.block(0, 0, 0, B.nloc), beta, C.local)
         return C
     dev = C.local.storage.device
-    if broadcast is None and dev.type == "cuda" and g.world > 1:
+    if broadcast is None and dev.type == "cuda" and (g.world > 1 or transport is not None):
         return _pgemm_device(alpha, A, B, beta, C, local_gemm, transport, stats)
     if broadcast is None:
         broadcast = device_broadcast

@@ -96,6 +96,8 @@ def choose(requested=None):
         raise ValueError(f"unknown transport {want!r}")
     if want != "auto":
         return want
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return "ipc"   # (nothing travels; no compute unit needs to be set aside)
     ok = 1
     peers = PeerMemory()
     try:

@@ -28,7 +28,7 @@ def _bcast():
     return device_broadcast if os.environ.get("EIGAMD_TEST_DEVICE_BCAST") else host_staged_broadcast
 
 
-def _worker(rank, world, port, kind, n, nb, transport=None):
+def _worker(rank, world, port, kind, n, nb, transport=None, backend="gloo"):
     import faulthandler
     import sys
     faulthandler.dump_traceback_later(90, exit=True)  # a stuck rank reports where, then exits
@@ -41,9 +41,16 @@ def _worker(rank, world, port, kind, n, nb, transport=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     torch.cuda.set_stream(torch.cuda.Stream())   # not the legacy default stream
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         grid = Grid()
+        if transport == "auto":   # the choice bench.py makes: a probe copy between neighbours, agreed on by all ranks
+            from eigen_amd.transport import choose
+            transport = choose("auto")
+            assert transport in ("ipc", "rccl")
+            if rank == 0:
+                print(f"transport chosen with {world} rank(s) on backend {backend}: {transport}")
+            transport = "rccl" if backend == "nccl" else transport   # (the branch this test is about)
         dt = [np.float32, np.float64, np.complex64, np.complex128][kind]
         A = DistMatrix(grid, n, n, nb, nb, kind).fill_uniform(1)
         B = DistMatrix(grid, n, n, nb, nb, kind).fill_uniform(2)
@@ -87,6 +94,20 @@ def test_pgemm_pull_transport_between_processes(world, kind, n, nb):
     """Every receiver copies the panel piece out of the owner's HBM (inter-process memory handles, a copy stream
     per process): the transport of the one-process-per-GPU driver, here with the processes sharing one GPU."""
     mp.spawn(_worker, args=(world, _free_port(), kind, n, nb, "ipc"), nprocs=world, join=True)
+
+
+def test_transport_chosen_by_probe_between_two_processes():
+    """EIGAMD_SUMMA_TRANSPORT=auto as bench.py uses it: every rank opens its neighbour's probe buffer and copies out of
+    it, the ranks agree (all-reduce MIN on the host group), and the product runs over what was chosen."""
+    mp.spawn(_worker, args=(2, _free_port(), 1, 1024, 128, "auto"), nprocs=2, join=True)
+
+
+def test_rccl_branch_with_one_rank():
+    """What can run of the RCCL transport on one GPU: backend "nccl" (= RCCL) with a world of one, the collective choice
+    of the transport, and the `rccl` branch of the device driver -- the local products on the stream that leaves compute
+    units to RCCL's kernels (eigamd_stream_create_cu_mask), ordered behind the copy stream by events.  With one rank
+    there is nothing to broadcast; the broadcasts themselves need more than one GPU."""
+    mp.spawn(_worker, args=(1, _free_port(), 1, 1536, 256, "auto", "nccl"), nprocs=1, join=True)
 
 
 def _lu_worker(rank, world, port, n, transport=None, kind=1):
