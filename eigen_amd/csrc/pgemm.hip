@@ -35,6 +35,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -700,9 +701,14 @@ int eigamd_pgemm_host(int dtype, int opa, int opb, int64_t m, int64_t n, int64_t
   };
   if (trace) fprintf(stderr, "pgemm_host: grid %dx%d created at %.2f ms\n", nprow, npcol, since());
   std::vector<std::thread> threads;
-  for (int d : devs) threads.emplace_back(device_thread, d);
   const double one[2] = {1.0, 0.0};
-  rc = run_prologue(*g);
+  try {
+    for (int d : devs) threads.emplace_back(device_thread, d);
+  } catch (const std::system_error& e) {   // (no thread to be had: the ones that did start are told to stop)
+    rc = abi_fail(EIGAMD_ERR_DEVICE, std::string("cannot start a copy thread: ") + e.what());
+    fail_with(rc);
+  }
+  if (rc == EIGAMD_OK) rc = run_prologue(*g);
   for (int64_t p = 0; rc == EIGAMD_OK && p < npanels; ++p) {
     {
       std::unique_lock<std::mutex> l(sh.mu);
