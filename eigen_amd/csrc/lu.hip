@@ -2388,7 +2388,12 @@ hipError_t make_streams(LuStreams& st, int base_workgroups, int per_cu, int* tot
   *total_cus = total;
   if (want > 0) {
     want = std::max(want, (base_workgroups + per_cu - 1) / per_cu);
-    want = (want + 7) / 8 * 8;
+    // In steps of 32: four compute units of every XCD, one per shader engine.  The dispatcher deals a launch's workgroups
+    // over the shader engines evenly whatever the mask says, so a mask that gives the engines unequal numbers of compute
+    // units leaves the fullest engine's last workgroups waiting for a place -- and the one-launch base case needs them all
+    // resident: with 48 units (6 per XCD) 96 workgroups of two per unit never came together (complex LU at 24576 rows),
+    // with 32 or 64 units an exact fit always has.
+    want = (want + 31) / 32 * 32;
     if (total % 32 != 0 || want * 2 > total) want = 0;  // not worth splitting: share the chip
   }
   if (st.panel && st.panel_cus == want) return hipSuccess;

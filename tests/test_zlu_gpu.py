@@ -168,3 +168,23 @@ def test_tall_panel_through_the_exchange_area():
     t2, nb2, r2 = ealu.blocked_lu(a2)
     check_against_oracle(a, a1, t1, a2, t2, exact_pivots=True)
     assert nb1 == nb2 and r1 == r2 == -1
+
+
+@pytest.mark.parametrize("dt,n", [(np.complex128, 20480), (np.complex64, 24576)])
+def test_panels_taller_than_the_default_panel_units_hold(dt, n):
+    """80 and 96 workgroups of the one-launch base case at two per compute unit: more than the 32 units the panel stream
+    has by default, so it gets more -- in steps of 32, because the workgroups of a launch are dealt evenly over the shader
+    engines and only such masks give every engine the same number of units (48 units never got the 96 workgroups resident
+    together).  Structure of the result and the residual on sampled rows."""
+    import torch
+    from eigen_amd.device import DeviceMatrix
+    from test_lu_config_gpu import sampled_lu_residual
+    kind = eigen_amd.C64 if dt == np.complex128 else eigen_amd.C32
+    a = DeviceMatrix(n, n, kind).fill_uniform(31)
+    transp, nb, fz = ealu.getrf_dev(a)
+    t = transp.cpu().numpy()
+    assert fz == -1 and (t >= np.arange(n)).all() and (t < n).all()
+    a0 = DeviceMatrix(n, n, kind).fill_uniform(31)
+    assert sampled_lu_residual(n, a, a0, t, nblocks=3) <= 8 * np.finfo(dt).eps * n
+    del a, a0
+    torch.cuda.empty_cache()
