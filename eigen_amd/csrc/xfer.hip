@@ -82,7 +82,10 @@ int eigamd_stream_create_cu_mask(int leave_free, int take_free, void** stream) {
   XF_HIP(hipGetDeviceProperties(&prop, dev));
   const int total = prop.multiProcessorCount;
   int n = leave_free > 0 ? leave_free : take_free;
-  n = (n + 7) / 8 * 8;   // the same number from every XCD (bit b of the mask: compute unit b / 8 of XCD b % 8)
+  // The same number from every XCD and from every shader engine of it (bit b of the mask: compute unit b / 8 of XCD b % 8;
+  // four engines per XCD): a launch's workgroups are dealt evenly over the engines whatever the mask says, so an engine
+  // left with fewer units than the others sets the pace for all of them -- hence steps of 32.
+  n = (n + 31) / 32 * 32;
   if (total % 32 != 0 || n * 2 > total) return abi_fail(EIGAMD_ERR_ARG, "cannot set that many compute units aside on this device");
   std::vector<uint32_t> mask((size_t)total / 32, 0u);
   for (int b = 0; b < total; ++b) {

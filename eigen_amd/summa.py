@@ -253,8 +253,9 @@ def _comm_stream(dev):
 
 def _product_stream(dev):
     """Stream of the local products under the RCCL transport: all compute units but EIGAMD_SUMMA_RCCL_CUS
-    (default 16, two per XCD; 0: the caller's stream, nothing set aside)."""
-    n = int(os.environ.get("EIGAMD_SUMMA_RCCL_CUS", "16"))
+    (default 32, one per shader engine of every XCD -- the library rounds up to that step; 0: the caller's stream,
+    nothing set aside)."""
+    n = int(os.environ.get("EIGAMD_SUMMA_RCCL_CUS", "32"))
     if n <= 0:
         return None
     key = (os.getpid(), dev.index, n)

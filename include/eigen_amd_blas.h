@@ -155,7 +155,7 @@ int eigamd_pgemm_destroy(eigamd_pgemm* handle);
  *
  * eigamd_stream_create_cu_mask: a stream whose kernels run on a subset of the compute units, the same
  * number from every XCD: with leave_free = n on all but n of them, with take_free = n on exactly those
- * n (rounded up to a multiple of 8).  The local products of the RCCL transport run on the first kind,
+ * n (rounded up to a multiple of 32: one unit per shader engine of every XCD).  The local products of the RCCL transport run on the first kind,
  * so that the compute units a broadcast kernel needs are never all held by product workgroups. */
 #define EIGAMD_IPC_HANDLE_BYTES 64
 int eigamd_ipc_export(const void* d_ptr, void* handle, int64_t* offset, int64_t* span);
