@@ -722,7 +722,12 @@ template <typename T> __device__ Candidate<T> block_best_all(T val, int row) {
 // (Four workgroups per compute unit for the real scalars; complex arithmetic needs more registers per row element
 // and gets the budget of two.)
 template <typename T> constexpr int fused_min_blocks() { return sizeof(Real<T>) != sizeof(T) ? 2 : 4; }
-template <typename T>
+// WIDE (up to kWideParts workgroups, elements of at most 8 bytes): while wavefront 0 polls the candidates, the other
+// three wavefronts read the ROWS of all the slots (and panel row jj) into LDS, so that the winner's row is already
+// there when the winner is known and the trip to memory that fetched it (0.76 us of a column's 4.1) leaves the chain.
+constexpr int kWideParts = 64;
+template <typename T> constexpr bool wide_poll_fits() { return sizeof(T) <= 8; }
+template <typename T, bool WIDE>
 __global__ void __launch_bounds__(kRowsPerBlock, fused_min_blocks<T>())
     lu_base_fused(T* __restrict__ P, int64_t ld, int rows, int jbw, int size, int* __restrict__ transp,
                   int row_offset, int col_global, BaseSlot<T>* __restrict__ slots, BaseTop<T>* __restrict__ tops,
@@ -731,6 +736,9 @@ __global__ void __launch_bounds__(kRowsPerBlock, fused_min_blocks<T>())
   __shared__ T s_top[kMaxBase];
   __shared__ unsigned s_pub[kRowsPerBlock / 64][kMaxBase * Words<T>::N];  // per wavefront: the words of the row it is about to publish
   __shared__ int s_win_row, s_flags;   // the winner's row; 1: the pivot is exactly zero, 2: gave up waiting
+  __shared__ T s_all[WIDE ? kWideParts + 1 : 1][kMaxBase];   // WIDE: the published row of every slot; [nparts]: panel row jj
+  __shared__ int s_gave_up;                                  // WIDE: a wavefront reading the rows gave up waiting
+  if (WIDE && threadIdx.x == 0) s_gave_up = 0;               // (read behind the barriers of the first column)
   constexpr int NW = Words<T>::N;          // words of a matrix element
   constexpr int NV = Words<Real<T>>::N;    // words of a candidate's size
   // The last workgroups of the grid take no part in the factorisation: rows of the enclosing panel's inverse and
@@ -800,6 +808,8 @@ __global__ void __launch_bounds__(kRowsPerBlock, fused_min_blocks<T>())
           if (e < kMaxBase * NW) {
             if (have) {
               payload = pub[e];
+              word = NV + 1 + e;
+            } else if (WIDE) {   // (the readers of the rows wait for every slot's words)
               word = NV + 1 + e;
             }
           } else if (e < kMaxBase * NW + NV) {
@@ -876,7 +886,7 @@ __global__ void __launch_bounds__(kRowsPerBlock, fused_min_blocks<T>())
       }
       const bool zero_w = !(val != (R)0);  // exactly zero
       const bool swap_w = !zero_w && prow != jj;
-      if (!failed) {
+      if (!WIDE && !failed) {
         const unsigned long long* src_top = top->data;
         const unsigned long long* src_win = buf[swap_w ? prow / kRowsPerBlock : 0].data;
         for (;;) {
@@ -907,10 +917,43 @@ __global__ void __launch_bounds__(kRowsPerBlock, fused_min_blocks<T>())
         s_win_row = prow;
         s_flags = (zero_w ? 1 : 0) | (failed ? 2 : 0);
       }
+    } else if (WIDE) {
+      // Value c of slot i is item 16 i + c; slot `nparts` stands for panel row jj.  A lane keeps asking for the items
+      // it has not seen with generation G yet; nothing in this loop involves another lane.
+      const int t = (int)threadIdx.x - 64, total = (nparts + 1) * kMaxBase;
+      constexpr int kReaders = kRowsPerBlock - 64;
+      constexpr int kItems = ((kWideParts + 1) * kMaxBase + kReaders - 1) / kReaders;
+      unsigned pending = 0;
+#pragma unroll
+      for (int u = 0; u < kItems; ++u)
+        if (t + u * kReaders < total) pending |= 1u << u;
+      unsigned spins = 0;
+      __builtin_amdgcn_s_sleep(EIGAMD_LU_POLL_DELAY);
+      while (pending) {
+#pragma unroll
+        for (int u = 0; u < kItems; ++u) {
+          if (pending & (1u << u)) {
+            const int e = t + u * kReaders, i = e / kMaxBase, c = e % kMaxBase;
+            const unsigned long long* src = (i == nparts ? top->data : buf[i].data) + c * NW;
+            T v;
+            if (get_value(src, v, G)) {
+              s_all[i][c] = v;
+              pending &= ~(1u << u);
+            }
+          }
+        }
+        if (!pending) break;
+        ++spins;
+        if (spins > kSpinLimit || ((spins & 255u) == 0 && coherent_load(error) != 0)) {
+          atomicOr(&s_gave_up, 1);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
     }
     __syncthreads();
     LU_TICK(4)
-    if (s_flags & 2) {
+    if ((s_flags & 2) || (WIDE && s_gave_up)) {
       if (threadIdx.x == 0) coherent_store(error, 1);
       alive = false;
     }
@@ -924,17 +967,20 @@ __global__ void __launch_bounds__(kRowsPerBlock, fused_min_blocks<T>())
       if (zero) atomicCAS(first_zero, -1, col_global + jj);  // keep the FIRST zero pivot (PartialPivLU.h:391-396)
       else if (swap) atomicAdd(nswaps, 1);
     }
+    // the pivot row after the exchange, and panel row jj before it
+    const T* piv = WIDE ? s_all[swap ? win.row / kRowsPerBlock : nparts] : s_u;
+    const T* old = WIDE ? s_all[nparts] : s_top;
     if (swap && valid && (r == win.row || r == jj)) {
-      const T* src = r == jj ? s_u : s_top;  // (never both: swap means win.row != jj)
+      const T* src = r == jj ? piv : old;  // (never both: swap means win.row != jj)
 #pragma unroll
       for (int c = 0; c < kMaxBase; ++c) row[c] = src[c];
     }
     if (valid && r > jj) {
       T l = row[jj];
-      if (!zero) l = l / s_u[jj];  // the reference divides (lu.col(k).tail /= pivot, :389)
+      if (!zero) l = l / piv[jj];  // the reference divides (lu.col(k).tail /= pivot, :389)
       row[jj] = l;
 #pragma unroll
-      for (int c = jj + 1; c < kMaxBase; ++c) row[c] -= l * s_u[c];
+      for (int c = jj + 1; c < kMaxBase; ++c) row[c] -= l * piv[c];
     }
     }
     LU_TICK(5)
@@ -1763,6 +1809,7 @@ template <typename T> struct Workspace {
   unsigned* generation; // host-side running count of pivot columns handed to lu_base_fused
   int* error;
   int fused_capacity;   // workgroups of lu_base_fused that are certainly resident together
+  int wide_poll_min = 2;  // lu_base_fused reads all rows beside the poll from this many workgroups on (EIGAMD_LU_WIDE_POLL=0: never)
   BaseCaseRule rule;
   int64_t wide_fixed, wide_t4, wide_t2;  // outer-step width rule of the look-ahead (outer_block)
   int64_t slice_cols, slice_min;  // the panel stream updates the last slice_cols columns itself while >= slice_min remain (0: off)
@@ -1799,8 +1846,16 @@ hipError_t unblocked(T* P, int64_t ld, int64_t rows, int jbw, int* transp, int r
   if (nparts <= w.fused_capacity && w.rule.fused) {   // (the base case's own workgroups are dispatched first)
     const unsigned gen0 = *w.generation;
     *w.generation += (unsigned)size;
-    hipLaunchKernelGGL(lu_base_fused<T>, dim3(nparts + njob), dim3(kRowsPerBlock), 0, s, P, ld, (int)rows, jbw, size, transp,
-                       row_offset, col_offset, w.slots, w.tops, gen0, w.error, w.first_zero, w.nswaps, ride);
+    bool wide = false;
+    if constexpr (wide_poll_fits<T>()) wide = nparts <= kWideParts && nparts >= w.wide_poll_min;
+    if constexpr (wide_poll_fits<T>()) {
+      if (wide)
+        hipLaunchKernelGGL((lu_base_fused<T, true>), dim3(nparts + njob), dim3(kRowsPerBlock), 0, s, P, ld, (int)rows, jbw, size, transp,
+                           row_offset, col_offset, w.slots, w.tops, gen0, w.error, w.first_zero, w.nswaps, ride);
+    }
+    if (!wide)
+      hipLaunchKernelGGL((lu_base_fused<T, false>), dim3(nparts + njob), dim3(kRowsPerBlock), 0, s, P, ld, (int)rows, jbw, size, transp,
+                         row_offset, col_offset, w.slots, w.tops, gen0, w.error, w.first_zero, w.nswaps, ride);
     return hipGetLastError();
   }
   if (ride.far_groups()) hipLaunchKernelGGL(lu_rowops_rank_update<T>, dim3((unsigned)ride.far_groups()), dim3(256), 0, s, ride.far);
@@ -2539,7 +2594,13 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   // streams of a process, and a second set kept alive would share them with the first.)
   const bool panel_bound = std::min(m, n) <= 16384;
   LuStreams& streams = sc.streams;
-  LU_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lu_base_fused<T>, kRowsPerBlock, 0));
+  LU_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (lu_base_fused<T, false>), kRowsPerBlock, 0));
+  if constexpr (wide_poll_fits<T>()) {
+    int per_cu_wide = 0;
+    LU_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_wide, (lu_base_fused<T, true>), kRowsPerBlock, 0));
+    per_cu = std::min(per_cu, per_cu_wide);
+  }
+  if (const char* e = getenv("EIGAMD_LU_WIDE_POLL")) w.wide_poll_min = atoi(e) > 0 ? atoi(e) : kWideParts + 1;
   per_cu = std::max(per_cu, 1);
   if (max_block > 16) {
     LU_TRY(make_streams(streams, (int)(nparts - 1), per_cu, &total_cus, panel_bound ? 64 : 32));
