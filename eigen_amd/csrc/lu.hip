@@ -722,11 +722,10 @@ template <typename T> __device__ Candidate<T> block_best_all(T val, int row) {
 // (Four workgroups per compute unit for the real scalars; complex arithmetic needs more registers per row element
 // and gets the budget of two.)
 template <typename T> constexpr int fused_min_blocks() { return sizeof(Real<T>) != sizeof(T) ? 2 : 4; }
-// WIDE (up to kWideParts workgroups, elements of at most 8 bytes): while wavefront 0 polls the candidates, the other
+// WIDE (up to kWideParts workgroups): while wavefront 0 polls the candidates, the other
 // three wavefronts read the ROWS of all the slots (and panel row jj) into LDS, so that the winner's row is already
 // there when the winner is known and the trip to memory that fetched it (0.76 us of a column's 4.1) leaves the chain.
 constexpr int kWideParts = 64;
-template <typename T> constexpr bool wide_poll_fits() { return sizeof(T) <= 8; }
 template <typename T, bool WIDE>
 __global__ void __launch_bounds__(kRowsPerBlock, fused_min_blocks<T>())
     lu_base_fused(T* __restrict__ P, int64_t ld, int rows, int jbw, int size, int* __restrict__ transp,
@@ -1004,15 +1003,19 @@ __global__ void __launch_bounds__(kRowsPerBlock, fused_min_blocks<T>())
 #undef LU_TICK
 }
 
-// The same base case for panels of at most single_rows() rows, in ONE workgroup of 1024 threads
+// The same base case for panels of at most single_rows() rows, in ONE workgroup of 512 threads
 // with single_rpt() rows per thread: the pivot search and the exchange of the two rows go through
 // LDS and two workgroup barriers per column, no global memory and no other workgroup is involved
-// (a column costs about 1 us here against 3.5 us or more through the exchange area).  Same
-// arithmetic as lu_base_fused, operation for operation.
-// (Two rows per thread for the real scalars, one for the complex ones: 16 waves on a compute unit have 128
-// registers each.)
-constexpr int kSingleThreads = 1024;
-template <typename T> constexpr int single_rpt() { return sizeof(Real<T>) != sizeof(T) ? 1 : 2; }
+// (a column costs 1.5 to 2.4 us here, by the number of rows, against 2.7 to 4 us through the exchange
+// area).  Same arithmetic as lu_base_fused, operation for operation.
+// (Four rows per thread for the real scalars, two for the complex ones.  Measured against 1024 threads
+// with two and one -- 2048^2 double 8.1 -> 7.5 ms, complex float 10.9 -> 10.2, the others unchanged -- and
+// against 256 threads with eight and four, which is slower throughout: 9.3 ms.)
+#ifndef EIGAMD_LU_SINGLE_THREADS
+#define EIGAMD_LU_SINGLE_THREADS 512
+#endif
+constexpr int kSingleThreads = EIGAMD_LU_SINGLE_THREADS;
+template <typename T> constexpr int single_rpt() { return (sizeof(Real<T>) != sizeof(T) ? 1024 : 2048) / kSingleThreads; }
 template <typename T> constexpr int single_rows() { return kSingleThreads * single_rpt<T>(); }
 template <typename T>
 __global__ void __launch_bounds__(kSingleThreads)
@@ -1846,14 +1849,10 @@ hipError_t unblocked(T* P, int64_t ld, int64_t rows, int jbw, int* transp, int r
   if (nparts <= w.fused_capacity && w.rule.fused) {   // (the base case's own workgroups are dispatched first)
     const unsigned gen0 = *w.generation;
     *w.generation += (unsigned)size;
-    bool wide = false;
-    if constexpr (wide_poll_fits<T>()) wide = nparts <= kWideParts && nparts >= w.wide_poll_min;
-    if constexpr (wide_poll_fits<T>()) {
-      if (wide)
-        hipLaunchKernelGGL((lu_base_fused<T, true>), dim3(nparts + njob), dim3(kRowsPerBlock), 0, s, P, ld, (int)rows, jbw, size, transp,
-                           row_offset, col_offset, w.slots, w.tops, gen0, w.error, w.first_zero, w.nswaps, ride);
-    }
-    if (!wide)
+    if (nparts <= kWideParts && nparts >= w.wide_poll_min)
+      hipLaunchKernelGGL((lu_base_fused<T, true>), dim3(nparts + njob), dim3(kRowsPerBlock), 0, s, P, ld, (int)rows, jbw, size, transp,
+                         row_offset, col_offset, w.slots, w.tops, gen0, w.error, w.first_zero, w.nswaps, ride);
+    else
       hipLaunchKernelGGL((lu_base_fused<T, false>), dim3(nparts + njob), dim3(kRowsPerBlock), 0, s, P, ld, (int)rows, jbw, size, transp,
                          row_offset, col_offset, w.slots, w.tops, gen0, w.error, w.first_zero, w.nswaps, ride);
     return hipGetLastError();
@@ -2595,7 +2594,7 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   const bool panel_bound = std::min(m, n) <= 16384;
   LuStreams& streams = sc.streams;
   LU_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (lu_base_fused<T, false>), kRowsPerBlock, 0));
-  if constexpr (wide_poll_fits<T>()) {
+  {
     int per_cu_wide = 0;
     LU_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_wide, (lu_base_fused<T, true>), kRowsPerBlock, 0));
     per_cu = std::min(per_cu, per_cu_wide);

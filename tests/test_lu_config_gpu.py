@@ -162,7 +162,27 @@ def test_per_column_kernel_chain_vs_oracle(dt):
         check_against_oracle(a, a1, t1, a2, t2, exact_pivots=dt == np.float64)
 
 
-@pytest.mark.parametrize("knobs", [dict(EIGAMD_LU_FUSED=0, EIGAMD_LU_SINGLE=0), dict(EIGAMD_LU_SINGLE=0), dict()])
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_both_forms_of_the_one_launch_base_case_give_the_same_bits(dt):
+    """The one-launch base case either fetches the winner's row once the winner is known or has three of its wavefronts read
+    every candidate's row beside the poll (up to 64 workgroups; EIGAMD_LU_WIDE_POLL=0 switches that off): same pivots as
+    the oracle and the same factors bit for bit, with one-workgroup base cases (the default below 2048 rows) and without."""
+    for (m, n) in [(2304, 2304), (5000, 300), (700, 700)]:
+        a = eigen_amd.fill_uniform_host(dt, m, n, 21 + m)
+        a0, a1, a2, a3 = (a.copy(order="F") for _ in range(4))
+        t0, nb0, r0 = oracle_lu(a0)
+        t1, nb1, r1 = ealu.blocked_lu(a1)
+        with env(EIGAMD_LU_WIDE_POLL=0):
+            t2, nb2, r2 = ealu.blocked_lu(a2)
+        with env(EIGAMD_LU_SINGLE=0):
+            t3, nb3, r3 = ealu.blocked_lu(a3)
+        assert r0 == r1 == r2 == r3 == -1
+        check_against_oracle(a, a0, t0, a1, t1, exact_pivots=dt == np.float64)
+        assert np.array_equal(t1, t2) and np.array_equal(t1, t3) and nb1 == nb2 == nb3
+        assert np.array_equal(a1, a2) and np.array_equal(a1, a3)
+
+
+@pytest.mark.parametrize("knobs", [dict(EIGAMD_LU_FUSED=0, EIGAMD_LU_SINGLE=0), dict(EIGAMD_LU_SINGLE=0), dict(EIGAMD_LU_SINGLE=0, EIGAMD_LU_WIDE_POLL=0), dict()])
 def test_column_of_nans_takes_the_diagonal_entry(knobs):
     """No comparable candidate in a column: every base case keeps the diagonal entry as the pivot,
     exchanges nothing and stays inside the matrix (transposition = the column's own index)."""

@@ -93,10 +93,12 @@ def test_device_resident_4096(dt):
 # Every base case and every switch of the driver, for the complex scalars: the per-column kernel chain, the one-launch
 # base case on short panels, the inverse built behind the panel, in-place solves of the next block's columns, the far
 # part of a block's update as a launch of its own, row operations and rank update as two launches, substitution in
-# place of every inverse, forced wide outer steps, the trailing update on two streams.
+# place of every inverse, forced wide outer steps, the trailing update on two streams, the one-launch base case without the
+# candidates' rows read beside the poll.
 SWITCHES = [dict(EIGAMD_LU_FUSED=0, EIGAMD_LU_SINGLE=0), dict(EIGAMD_LU_SINGLE=0), dict(EIGAMD_LU_INVERSE_ON_THE_WAY=0),
             dict(EIGAMD_LU_SOLVE_TMP=0), dict(EIGAMD_LU_FAR_RIDES=0), dict(EIGAMD_LU_FUSED_ROWOPS=0),
-            dict(EIGAMD_LU_INVERSE_LIMIT=0), dict(EIGAMD_LU_WIDE=512), dict(EIGAMD_LU_SPLIT_MIN=256, EIGAMD_LU_WIDE=256)]
+            dict(EIGAMD_LU_INVERSE_LIMIT=0), dict(EIGAMD_LU_WIDE=512), dict(EIGAMD_LU_SPLIT_MIN=256, EIGAMD_LU_WIDE=256),
+            dict(EIGAMD_LU_WIDE_POLL=0), dict(EIGAMD_LU_WIDE_POLL=0, EIGAMD_LU_SINGLE=0)]
 
 
 _ORACLE = {}
