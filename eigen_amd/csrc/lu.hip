@@ -721,7 +721,7 @@ template <typename T> __device__ Candidate<T> block_best_all(T val, int row) {
 // *error and leaves; so does every workgroup that then sees the flag: the grid always drains.
 // (Four workgroups per compute unit for the real scalars; complex arithmetic needs more registers per row element
 // and gets the budget of two.)
-template <typename T> constexpr int fused_min_blocks() { return sizeof(Real<T>) != sizeof(T) ? 2 : 4; }
+template <typename T> constexpr int fused_min_blocks() { return (sizeof(Real<T>) != sizeof(T) ? 2 : 4) * 256 / kRowsPerBlock; }
 // WIDE (up to kWideParts workgroups): while wavefront 0 polls the candidates, the other
 // three wavefronts read the ROWS of all the slots (and panel row jj) into LDS, so that the winner's row is already
 // there when the winner is known and the trip to memory that fetched it (0.76 us of a column's 4.1) leaves the chain.
@@ -744,7 +744,7 @@ __global__ void __launch_bounds__(kRowsPerBlock, fused_min_blocks<T>())
   // the far part of the block before's update (Ride), in the time the others spend on their sixteen exchanges.
   const int nparts = (int)gridDim.x - ride.inv_groups() - ride.far_groups();
   if ((int)blockIdx.x >= nparts) {
-    run_ride<T>(ride, (int)blockIdx.x - nparts);
+    if (threadIdx.x < 256) run_ride<T>(ride, (int)blockIdx.x - nparts);   // (those workgroups work with 256 threads)
     return;
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
