@@ -499,7 +499,7 @@ def main():
         how = ("every receiver copies the piece out of its owner's HBM (inter-process memory handles, DMA engines)"
                if transport == "ipc" else
                f"RCCL broadcasts on row / column communicators, local products on a stream that leaves "
-               f"{os.environ.get('EIGAMD_SUMMA_RCCL_CUS', '16')} compute units free")
+               f"{os.environ.get('EIGAMD_SUMMA_RCCL_CUS', '32')} compute units free")
         layout = f"2-D block-cyclic {grid.nprow}x{grid.npcol}, block {nb}, SUMMA one panel ahead; {how}"
 
     for _ in range(warmup):
@@ -604,8 +604,10 @@ def main():
             "parity_max_test_ratio": round(ratio, 3),
             "parity_limit": 16.0,
             "roofline": {"bound": "mfma", "achieved": round(kernel_tflops, 3), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(kernel_tflops / peak, 4), "traffic": measured_traffic(args.dtype, n)[0],
-                         "traffic_source": measured_traffic(args.dtype, n)[1],
+                         "frac": round(kernel_tflops / peak, 4),
+                         # (the counters were collected for the single-device launch; a rank's local products are other launches)
+                         "traffic": measured_traffic(args.dtype, n)[0] if world == 1 else None,
+                         "traffic_source": measured_traffic(args.dtype, n)[1] if world == 1 else None,
                          "kernel": f"eigamd::gemm_kernel<{args.dtype}, A m-contiguous, B k-contiguous>",
                          "algorithmic_bytes_per_launch": 4.0 * n * n * {"f32": 4, "f64": 8, "c32": 8, "c64": 16}[args.dtype]
                          if world == 1 else None,
