@@ -3,8 +3,10 @@
 Four ranks on the one device share its host link, so what the grid's host route can gain or lose against the
 single-device route is overlap alone: operands uploaded in the order the reduction consumes them, the products
 underneath the later uploads, C back as soon as the last product has run (blas/level3_impl.h:12-76 is one call either
-way; the reference hides its split over the cores the same way, Parallelizer.h:101-176).  Within 15 % at 8192^3, best of
-five each.  A fresh process because that is what a caller's process looks like: inside the test session dozens of
+way; the reference hides its split over the cores the same way, Parallelizer.h:101-176).  Best of five each at 8192^3;
+the bound is 1.5: with nothing overlapped (all of A, B and C up, then the products, then C back) the grid's route takes
+2.3 times the single-device route's 44 ms, overlapped it takes 1.0 to 1.2 times by how busy the box's host cores are
+(four copy threads and their staging share them: 44.5 against 44.1 ms on one box, 53.3 against 44.1 on another).  A fresh process because that is what a caller's process looks like: inside the test session dozens of
 streams of earlier tests (the LU's compute-unit-masked ones among them) share the process's few hardware queues with
 the grid's and take the overlap away (63 ms against 45 there; 46.6 against 44 alone).  Collected late for the same
 reason a timing belongs at the end: a slow box must not hide the parity tests behind it."""
@@ -58,4 +60,4 @@ def test_host_route_over_a_grid_overlaps_its_copies_with_its_products():
     r = json.loads(line[len("RESULT "):])
     print(f"dgemm_ 8192^3 from host memory: one device {r['t_one'] * 1e3:.1f} ms, 2x2 ranks on the same device {r['t_grid'] * 1e3:.1f} ms")
     assert r["ratio"] < 16.0
-    assert r["t_grid"] <= 1.15 * r["t_one"], r
+    assert r["t_grid"] <= 1.5 * r["t_one"], r
