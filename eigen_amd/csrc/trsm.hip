@@ -102,10 +102,17 @@ __device__ __forceinline__ void note_max(unsigned long long* word, double v) {
   }
   if ((threadIdx.x & 63) == 0 && b != 0) atomicMax(word, b);
 }
+// Where the image of block b lies.  Alone: X + b NB^2, leading dimension NB.  In pairs: blocks 2p and 2p + 1 are the
+// diagonal quadrants of a 2 NB x 2 NB image at X + p (2 NB)^2 (leading dimension 2 NB) whose other two quadrants are
+// zero and, once trtri_pair_product has run, the off-diagonal block of the inverse of the pair's 2 NB x 2 NB triangle.
+template <typename T, int NB> __device__ __forceinline__ T* image_of(T* X, int b, int pairs) {
+  return pairs ? X + (int64_t)(b >> 1) * (4 * NB * NB) + (b & 1) * (NB + (int64_t)NB * 2 * NB) : X + (int64_t)b * NB * NB;
+}
 template <typename T, int NB>
 __global__ void __launch_bounds__(256) trtri_blocks(const T* __restrict__ A, int64_t lda, int na, int upper, int unit,
-                                                    T* __restrict__ X, unsigned long long* __restrict__ gmax) {
+                                                    T* __restrict__ X, unsigned long long* __restrict__ gmax, int pairs) {
   constexpr int kNB = NB;   // block extent of this instantiation
+  const int ldx = pairs ? 2 * NB : NB;
   __shared__ T s_x[kInvCols][kNB + 1];
   __shared__ T s_acc[kInvCols][kInvCols + 1];
   __shared__ T s_d[kInvCols][kInvCols + 1];  // s_d[k - i0][i - i0] = L(i, k) of the diagonal 32 x 32
@@ -113,7 +120,7 @@ __global__ void __launch_bounds__(256) trtri_blocks(const T* __restrict__ A, int
   const int b0 = blockIdx.y * kNB;
   const int bs = min(kNB, na - b0);
   const T* Ab = A + b0 + (int64_t)b0 * lda;
-  T* Xb = X + (int64_t)blockIdx.y * kNB * kNB;
+  T* Xb = image_of<T, NB>(X, (int)blockIdx.y, pairs);
   auto at = [&](int i, int k) { return upper ? Ab[k + (int64_t)i * lda] : Ab[i + (int64_t)k * lda]; };  // i > k
   const int first = blockIdx.x * kInvCols;
   for (int idx = threadIdx.x; idx < kInvCols * kNB; idx += 256) s_x[idx / kNB][idx % kNB] = zero_of<T>();
@@ -170,8 +177,8 @@ __global__ void __launch_bounds__(256) trtri_blocks(const T* __restrict__ A, int
     const int c = idx / kNB, i = idx % kNB;
     const int g = first + c;
     const T v = (g < bs && i < bs) ? s_x[c][i] : zero_of<T>();
-    if (upper) Xb[g + (int64_t)i * kNB] = v;
-    else Xb[i + (int64_t)g * kNB] = v;
+    if (upper) Xb[g + (int64_t)i * ldx] = v;
+    else Xb[i + (int64_t)g * ldx] = v;
     const double vm = mag(v);
     mx = (vm > mx || vm != vm) ? vm : mx;
     if (g < bs && i < bs && (i > g || (i == g && !unit))) {   // the stored triangle, this workgroup's columns
@@ -181,6 +188,80 @@ __global__ void __launch_bounds__(256) trtri_blocks(const T* __restrict__ A, int
   }
   note_max(gmax + 2 * blockIdx.y, mx);
   note_max(gmax + 2 * blockIdx.y + 1, ma);
+  // In pairs: the quadrant of the pair's image that stays zero is written by the block that shares its columns (a lower
+  // triangle's inverse: rows of the first block, columns of the second) or its rows (upper).
+  if (pairs && (int)(blockIdx.y & 1) == (upper ? 0 : 1)) {
+    for (int idx = threadIdx.x; idx < kInvCols * kNB; idx += 256) {
+      const int c = idx / kNB, i = idx % kNB;
+      const int g = first + c;
+      if (upper) Xb[(kNB + i) + (int64_t)g * ldx] = zero_of<T>();   // (second block's rows, this block's columns)
+      else Xb[(i - kNB) + (int64_t)g * ldx] = zero_of<T>();         // (first block's rows, this block's columns)
+    }
+  }
+}
+
+// One stage of the off-diagonal block of a pair's inverse, for all pairs in one launch: C_p = (-)P_p Q_p, NB x NB x NB
+// each, operands `sP`, `sQ`, `sC` elements apart from pair to pair.  inv([T11 0; T21 T22]) has -inv(T22) T21 inv(T11)
+// below the diagonal: stage 1 forms T21 inv(T11) into scratch, stage 2 multiplies by -inv(T22) into the image (an upper
+// triangle likewise above the diagonal).  The images are whole NB x NB blocks with zeros where the triangle ends, so
+// only the block of A needs its extent: rows >= p_rows or columns >= p_cols of P (and likewise of Q) read as zero in the
+// LAST pair, which is the one a ragged matrix cuts short.  grid = ((NB / 32)^2, pairs); a workgroup owns a 32 x 32 tile
+// of C (thread: rows ti, ti + 16, columns 2 tj, 2 tj + 1) and walks k sixteen at a time, one chunk of loads ahead.
+template <typename T>
+__global__ void __launch_bounds__(256) trtri_pair_product(const T* __restrict__ P, int64_t ldp, int64_t sP, int p_rows, int p_cols,
+                                                          const T* __restrict__ Q, int64_t ldq, int64_t sQ, int q_rows, int q_cols,
+                                                          T* __restrict__ C, int64_t ldc, int64_t sC, int nb, int negate) {
+  constexpr int kT = 32, kK = 16;
+  __shared__ T s_a[kK][kT + 1];   // s_a[kk][i] = P(r0 + i, k0 + kk)
+  __shared__ T s_b[kK][kT + 2];   // s_b[kk][j] = Q(k0 + kk, c0 + j)
+  const int pair = blockIdx.y;
+  const bool last = pair == (int)gridDim.y - 1;
+  const int pr = last ? p_rows : nb, pc = last ? p_cols : nb, qr = last ? q_rows : nb, qc = last ? q_cols : nb;
+  const int per_row = nb / kT;
+  const int r0 = ((int)blockIdx.x % per_row) * kT, c0 = ((int)blockIdx.x / per_row) * kT;
+  P += (int64_t)pair * sP;
+  Q += (int64_t)pair * sQ;
+  C += (int64_t)pair * sC;
+  const int t = threadIdx.x, ti = t % 16, tj = t / 16;
+  // loads of a chunk: P 32 x 16 (two per thread, consecutive threads down a column), Q 16 x 32 (two per thread)
+  const int ai = t % kT, ak = t / kT;          // and ak + 8
+  const int bk = t % kK, bj = t / kK;          // and bj + 16
+  T ra[2], rb[2];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row = r0 + ai, col = k0 + ak + 8 * u;
+      ra[u] = (row < pr && col < pc) ? P[row + (int64_t)col * ldp] : zero_of<T>();
+      const int qrow = k0 + bk, qcol = c0 + bj + 16 * u;
+      rb[u] = (qrow < qr && qcol < qc) ? Q[qrow + (int64_t)qcol * ldq] : zero_of<T>();
+    }
+  };
+  T acc[2][2] = {{zero_of<T>(), zero_of<T>()}, {zero_of<T>(), zero_of<T>()}};
+  fetch(0);
+  for (int k0 = 0; k0 < nb; k0 += kK) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      s_a[ak + 8 * u][ai] = ra[u];
+      s_b[bk][bj + 16 * u] = rb[u];
+    }
+    __syncthreads();
+    if (k0 + kK < nb) fetch(k0 + kK);
+#pragma unroll
+    for (int kk = 0; kk < kK; ++kk) {
+      const T a0 = s_a[kk][ti], a1 = s_a[kk][ti + 16];
+      const T b0 = s_b[kk][2 * tj], b1 = s_b[kk][2 * tj + 1];
+      acc[0][0] = acc[0][0] + a0 * b0; acc[0][1] = acc[0][1] + a0 * b1;
+      acc[1][0] = acc[1][0] + a1 * b0; acc[1][1] = acc[1][1] + a1 * b1;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const T v = acc[q][e];
+      C[(r0 + ti + 16 * q) + (int64_t)(c0 + 2 * tj + e) * ldc] = negate ? -v : v;
+    }
 }
 
 
@@ -189,8 +270,9 @@ __global__ void __launch_bounds__(256) trtri_blocks(const T* __restrict__ A, int
 // grid = number of blocks, 256 threads.
 template <typename T, int NB>
 __global__ void __launch_bounds__(256) trtri_decide(T* __restrict__ X, double limit, const unsigned long long* __restrict__ gmax,
-                                                    int* __restrict__ flags) {
-  T* Xb = X + (int64_t)blockIdx.x * NB * NB;
+                                                    int* __restrict__ flags, int pairs) {
+  T* Xb = image_of<T, NB>(X, (int)blockIdx.x, pairs);
+  const int ldx = pairs ? 2 * NB : NB;
   __shared__ int s_subst;
   if (threadIdx.x == 0) {
     const double mx = __longlong_as_double((long long)gmax[2 * blockIdx.x]);
@@ -201,7 +283,8 @@ __global__ void __launch_bounds__(256) trtri_decide(T* __restrict__ X, double li
   __syncthreads();
   const bool subst = s_subst != 0;
   if (subst)
-    for (int idx = threadIdx.x; idx < NB * NB; idx += 256) Xb[idx] = (idx % NB == idx / NB) ? One<T>::v() : zero_of<T>();
+    for (int idx = threadIdx.x; idx < NB * NB; idx += 256)
+      Xb[idx % NB + (int64_t)(idx / NB) * ldx] = (idx % NB == idx / NB) ? One<T>::v() : zero_of<T>();
 }
 
 // One diagonal block by substitution, in place, for the blocks trtri_decide flagged (others: the
@@ -335,6 +418,17 @@ hipError_t trsm_device(int kind, bool left, bool upper, int op, bool unit, int64
   static const bool leaf_copy = [] { const char* e = getenv("EIGAMD_TRSM_LEAF_COPY"); return !(e && atoi(e) == 0); }();
   const int64_t kNB = (leaf_copy && (kind == F64 || kind == F32)) ? kLargeNB : block_extent(kind, left);
   const int64_t nblk = (na + kNB - 1) / kNB;
+  // Leaves of TWO diagonal blocks: the inverse of a pair's 2 kNB x 2 kNB triangle is put together from the two
+  // blocks' inverses (-inv(T22) T21 inv(T11) off the diagonal, two small products for all pairs at once:
+  // trtri_pair_product), and a leaf is one product with it where there were two leaves and the update between them --
+  // three products of 256 x nrhs x 256, each a launch of few tiles with a cut reduction, become one of 512 x nrhs x 512.
+  // A block that is solved by substitution has the identity for its inverse, the pair's off-diagonal block then holds
+  // what is left of the update, and the substitutions run in front of the product (the block solved first) and behind
+  // it (the other one).  EIGAMD_TRSM_PAIRS=0: leaves of one block.
+  static const bool pairs_wanted = [] { const char* e = getenv("EIGAMD_TRSM_PAIRS"); return !(e && atoi(e) == 0); }();
+  const bool pairs = leaf_copy && pairs_wanted && nblk >= 2;
+  const int64_t unit_blocks = pairs ? 2 : 1, kUnit = unit_blocks * kNB;
+  const int64_t nunits = (nblk + unit_blocks - 1) / unit_blocks;
   const char* Ab = static_cast<const char*>(A);
   char* Bb = static_cast<char*>(B);
   auto a_at = [&](int64_t r, int64_t c) { return Ab + (r + c * lda) * es; };
@@ -343,10 +437,11 @@ hipError_t trsm_device(int kind, bool left, bool upper, int op, bool unit, int64
   // inverses of all diagonal blocks (scratch shared by all callers: a use waits for the last one)
   InvScratch& sc = inv_scratch();
   std::lock_guard<std::mutex> lock(sc.mu);
-  const size_t inv_bytes = (size_t)nblk * kNB * kNB * es;
+  const size_t pair_tmp_bytes = pairs ? (size_t)nunits * kNB * kNB * es : 0;   // T21 inv(T11) of every pair, between the two stages
+  const size_t inv_bytes = (size_t)nunits * kUnit * kUnit * es + pair_tmp_bytes;
   const size_t max_bytes = ((size_t)nblk * 2 * sizeof(unsigned long long) + 255) / 256 * 256;   // max|inv(T_b)|, max|T_b|
   const size_t flag_bytes = ((size_t)nblk * sizeof(int) + 255) / 256 * 256 + max_bytes;
-  const size_t leaf_bytes = leaf_copy ? (size_t)(left ? n : m) * kNB * es : 0;   // one leaf's result
+  const size_t leaf_bytes = leaf_copy ? (size_t)(left ? n : m) * kUnit * es : 0;   // one leaf's result
   const size_t need = inv_bytes + flag_bytes + leaf_bytes;
   if (!sc.done) TR_TRY(hipEventCreateWithFlags(&sc.done, hipEventDisableTiming));
   if (need > sc.cap) {
@@ -370,32 +465,32 @@ hipError_t trsm_device(int kind, bool left, bool upper, int op, bool unit, int64
     case F32:
       if (kNB == kLargeNB)
         hipLaunchKernelGGL((trtri_blocks<float, kLargeNB>), grid, dim3(256), 0, s, static_cast<const float*>(A), lda, (int)na, up,
-                           un, static_cast<float*>(sc.buf), gmax);
+                           un, static_cast<float*>(sc.buf), gmax, pairs ? 1 : 0);
       else
         hipLaunchKernelGGL((trtri_blocks<float, kSmallNB>), grid, dim3(256), 0, s, static_cast<const float*>(A), lda, (int)na, up,
-                           un, static_cast<float*>(sc.buf), gmax);
+                           un, static_cast<float*>(sc.buf), gmax, pairs ? 1 : 0);
       break;
     case F64:
       if (kNB == kLargeNB)
         hipLaunchKernelGGL((trtri_blocks<double, kLargeNB>), grid, dim3(256), 0, s, static_cast<const double*>(A), lda, (int)na,
-                           up, un, static_cast<double*>(sc.buf), gmax);
+                           up, un, static_cast<double*>(sc.buf), gmax, pairs ? 1 : 0);
       else
         hipLaunchKernelGGL((trtri_blocks<double, kSmallNB>), grid, dim3(256), 0, s, static_cast<const double*>(A), lda, (int)na,
-                           up, un, static_cast<double*>(sc.buf), gmax);
+                           up, un, static_cast<double*>(sc.buf), gmax, pairs ? 1 : 0);
       break;
     case C32:
       hipLaunchKernelGGL((trtri_blocks<Cplx<float>, kSmallNB>), grid, dim3(256), 0, s, static_cast<const Cplx<float>*>(A), lda,
-                         (int)na, up, un, static_cast<Cplx<float>*>(sc.buf), gmax);
+                         (int)na, up, un, static_cast<Cplx<float>*>(sc.buf), gmax, pairs ? 1 : 0);
       break;
     default:
       hipLaunchKernelGGL((trtri_blocks<Cplx<double>, kSmallNB>), grid, dim3(256), 0, s, static_cast<const Cplx<double>*>(A), lda,
-                         (int)na, up, un, static_cast<Cplx<double>*>(sc.buf), gmax);
+                         (int)na, up, un, static_cast<Cplx<double>*>(sc.buf), gmax, pairs ? 1 : 0);
       break;
   }
   TR_TRY(hipGetLastError());
   const double limit = growth_limit();
 #define EIGAMD_DECIDE(TYPE, NBV) \
-  hipLaunchKernelGGL((trtri_decide<TYPE, NBV>), dim3((unsigned)nblk), dim3(256), 0, s, static_cast<TYPE*>(sc.buf), limit, gmax, flags)
+  hipLaunchKernelGGL((trtri_decide<TYPE, NBV>), dim3((unsigned)nblk), dim3(256), 0, s, static_cast<TYPE*>(sc.buf), limit, gmax, flags, pairs ? 1 : 0)
   switch (kind) {
     case F32: if (kNB == kLargeNB) EIGAMD_DECIDE(float, kLargeNB); else EIGAMD_DECIDE(float, kSmallNB); break;
     case F64: if (kNB == kLargeNB) EIGAMD_DECIDE(double, kLargeNB); else EIGAMD_DECIDE(double, kSmallNB); break;
@@ -404,7 +499,47 @@ hipError_t trsm_device(int kind, bool left, bool upper, int op, bool unit, int64
   }
 #undef EIGAMD_DECIDE
   TR_TRY(hipGetLastError());
-  auto inv = [&](int64_t j) { return static_cast<const char*>(sc.buf) + (size_t)j * kNB * kNB * es; };
+  if (pairs) {
+    // The off-diagonal blocks of the pairs' inverses (pairs that have a second block: nblk / 2 of them).
+    const int64_t np = nblk / 2;
+    const int last_hi = (int)std::min<int64_t>(kNB, na - (2 * np - 1) * kNB);   // extent of the last pair's second block
+    char* images = static_cast<char*>(sc.buf);
+    char* tmp = images + (size_t)nunits * kUnit * kUnit * es;
+    const int64_t s_img = kUnit * kUnit, s_tmp = kNB * kNB, s_a = 2 * kNB * (lda + 1);
+    const int64_t o_hi = kNB + kNB * kUnit;                       // the second block's quadrant inside an image
+    const int64_t o_off = upper ? kNB * kUnit : kNB;              // the off-diagonal quadrant that is not zero
+    const char* A_off = upper ? a_at(0, kNB) : a_at(kNB, 0);      // T12 or T21 of the first pair
+    const dim3 pgrid((unsigned)((kNB / 32) * (kNB / 32)), (unsigned)np);
+    const int nb = (int)kNB;
+#define EIGAMD_PAIR(TYPE)                                                                                                          \
+    {                                                                                                                              \
+      TYPE* img = reinterpret_cast<TYPE*>(images);                                                                                 \
+      TYPE* t = reinterpret_cast<TYPE*>(tmp);                                                                                      \
+      const TYPE* a = reinterpret_cast<const TYPE*>(A_off);                                                                        \
+      if (!upper) { /* tmp = T21 inv(T11); X21 = -inv(T22) tmp */                                                                  \
+        hipLaunchKernelGGL((trtri_pair_product<TYPE>), pgrid, dim3(256), 0, s, a, lda, s_a, last_hi, nb, img, kUnit, s_img, nb, nb, \
+                           t, kNB, s_tmp, nb, 0);                                                                                  \
+        hipLaunchKernelGGL((trtri_pair_product<TYPE>), pgrid, dim3(256), 0, s, img + o_hi, kUnit, s_img, nb, nb, t, kNB, s_tmp, nb, \
+                           nb, img + o_off, kUnit, s_img, nb, 1);                                                                  \
+      } else {      /* tmp = T12 inv(T22); X12 = -inv(T11) tmp */                                                                  \
+        hipLaunchKernelGGL((trtri_pair_product<TYPE>), pgrid, dim3(256), 0, s, a, lda, s_a, nb, last_hi, img + o_hi, kUnit, s_img,  \
+                           nb, nb, t, kNB, s_tmp, nb, 0);                                                                          \
+        hipLaunchKernelGGL((trtri_pair_product<TYPE>), pgrid, dim3(256), 0, s, img, kUnit, s_img, nb, nb, t, kNB, s_tmp, nb, nb,    \
+                           img + o_off, kUnit, s_img, nb, 1);                                                                      \
+      }                                                                                                                            \
+    }
+    if (np > 0) {
+      switch (kind) {
+        case F32: EIGAMD_PAIR(float); break;
+        case F64: EIGAMD_PAIR(double); break;
+        case C32: EIGAMD_PAIR(Cplx<float>); break;
+        default:  EIGAMD_PAIR(Cplx<double>); break;
+      }
+      TR_TRY(hipGetLastError());
+    }
+#undef EIGAMD_PAIR
+  }
+  auto inv = [&](int64_t u) { return static_cast<const char*>(sc.buf) + (size_t)u * kUnit * kUnit * es; };
   // One buffer for the pieces of every cut reduction of this solve (the solve is a chain of some dozens of products,
   // most of them of few tiles): taken from the library's pool once and given back at the end, instead of once per
   // product -- every hand-back records an event, and the marker costs the stream 5 us (dtrsm 4096: 31 of them).
@@ -450,8 +585,17 @@ hipError_t trsm_device(int kind, bool left, bool upper, int op, bool unit, int64
   const int64_t ext = na;
   rec.run = [&](int64_t j0, int64_t j1) -> hipError_t {
     if (j1 - j0 == 1) {
-      const int64_t p0 = j0 * kNB, pb = std::min<int64_t>(kNB, ext - p0);
-      TR_TRY(subst(j0, p0, pb));
+      const int64_t p0 = j0 * kUnit, pb = std::min<int64_t>(kUnit, ext - p0);
+      // the substitution form of the unit's blocks: the one solved first in front of the product, the other behind it
+      const bool two = pairs && pb > kNB;
+      const bool lo_first = left ? eff_lower : !eff_lower;
+      const int64_t b_first = unit_blocks * j0 + ((two && !lo_first) ? 1 : 0), b_second = unit_blocks * j0 + ((two && lo_first) ? 1 : 0);
+      auto block_subst = [&](int64_t b) { return subst(b, b * kNB, std::min<int64_t>(kNB, ext - b * kNB)); };
+      struct Behind {   // (the leaf returns from several places)
+        std::function<hipError_t()> f;
+        hipError_t run(hipError_t e) { return e != hipSuccess ? e : f(); }
+      } behind{[&]() -> hipError_t { return two ? block_subst(b_second) : hipSuccess; }};
+      TR_TRY(block_subst(b_first));
       if (leaf_copy) {  // the product into the scratch image (any tile may run it), then back
         // (Where the launcher cuts the leaf's reduction into pieces -- it does for most leaves: few tiles -- the pass
         // over the pieces writes B_j itself and there is nothing to copy: 16 us less per leaf, copy and the two gaps
@@ -459,23 +603,24 @@ hipError_t trsm_device(int kind, bool left, bool upper, int op, bool unit, int64
         char* leaf = static_cast<char*>(sc.buf) + inv_bytes + flag_bytes;
         bool direct = false;
         if (left) {
-          TR_TRY(gemm(kind, op, OP_N, pb, n, pb, 1.0, inv(j0), kNB, b_at(p0, 0), ldb, 0.0, leaf, pb, s, ws, ws ? ws_bytes : 0, b_at(p0, 0), ldb, &direct));
-          if (direct) return hipSuccess;
-          return hipMemcpy2DAsync(b_at(p0, 0), (size_t)ldb * es, leaf, (size_t)pb * es, (size_t)pb * es, (size_t)n,
-                                  hipMemcpyDeviceToDevice, s);
+          TR_TRY(gemm(kind, op, OP_N, pb, n, pb, 1.0, inv(j0), kUnit, b_at(p0, 0), ldb, 0.0, leaf, pb, s, ws, ws ? ws_bytes : 0, b_at(p0, 0), ldb, &direct));
+          if (direct) return behind.run(hipSuccess);
+          return behind.run(hipMemcpy2DAsync(b_at(p0, 0), (size_t)ldb * es, leaf, (size_t)pb * es, (size_t)pb * es, (size_t)n,
+                                             hipMemcpyDeviceToDevice, s));
         }
-        TR_TRY(gemm(kind, OP_N, op, m, pb, pb, 1.0, b_at(0, p0), ldb, inv(j0), kNB, 0.0, leaf, m, s, ws, ws ? ws_bytes : 0, b_at(0, p0), ldb, &direct));
-        if (direct) return hipSuccess;
-        return hipMemcpy2DAsync(b_at(0, p0), (size_t)ldb * es, leaf, (size_t)m * es, (size_t)m * es, (size_t)pb,
-                                hipMemcpyDeviceToDevice, s);
+        TR_TRY(gemm(kind, OP_N, op, m, pb, pb, 1.0, b_at(0, p0), ldb, inv(j0), kUnit, 0.0, leaf, m, s, ws, ws ? ws_bytes : 0, b_at(0, p0), ldb, &direct));
+        if (direct) return behind.run(hipSuccess);
+        return behind.run(hipMemcpy2DAsync(b_at(0, p0), (size_t)ldb * es, leaf, (size_t)m * es, (size_t)m * es, (size_t)pb,
+                                           hipMemcpyDeviceToDevice, s));
       }
+      // (in place: leaves of one block, kUnit == kNB)
       if (left)  // B_j <- op(inv_j) * B_j, in place (one tile row)
-        return gemm(kind, op, OP_N, pb, n, pb, 1.0, inv(j0), kNB, b_at(p0, 0), ldb, 0.0, b_at(p0, 0), ldb, s, ws, ws ? ws_bytes : 0);
+        return gemm(kind, op, OP_N, pb, n, pb, 1.0, inv(j0), kUnit, b_at(p0, 0), ldb, 0.0, b_at(p0, 0), ldb, s, ws, ws ? ws_bytes : 0);
       // B_j <- B_j * op(inv_j), in place (one tile column)
-      return gemm(kind, OP_N, op, m, pb, pb, 1.0, b_at(0, p0), ldb, inv(j0), kNB, 0.0, b_at(0, p0), ldb, s, ws, ws ? ws_bytes : 0);
+      return gemm(kind, OP_N, op, m, pb, pb, 1.0, b_at(0, p0), ldb, inv(j0), kUnit, 0.0, b_at(0, p0), ldb, s, ws, ws ? ws_bytes : 0);
     }
     const int64_t jm = j0 + (j1 - j0 + 1) / 2;
-    const int64_t lo0 = j0 * kNB, lo1 = jm * kNB, hi1 = std::min<int64_t>(j1 * kNB, ext);
+    const int64_t lo0 = j0 * kUnit, lo1 = jm * kUnit, hi1 = std::min<int64_t>(j1 * kUnit, ext);
     const int64_t nlo = lo1 - lo0, nhi = hi1 - lo1;
     const bool low_first = left ? eff_lower : !eff_lower;   // which half is solved first
     TR_TRY(low_first ? rec.run(j0, jm) : rec.run(jm, j1));
@@ -493,7 +638,7 @@ hipError_t trsm_device(int kind, bool left, bool upper, int op, bool unit, int64
     }
     return low_first ? rec.run(jm, j1) : rec.run(j0, jm);
   };
-  TR_TRY(rec.run(0, nblk));
+  TR_TRY(rec.run(0, nunits));
   TR_TRY(hipEventRecord(sc.done, s));
   if (!(alpha[0] == 1.0 && alpha[1] == 0.0)) {  // B *= alpha (level3_impl.h:174-175)
     GemmCall c;
