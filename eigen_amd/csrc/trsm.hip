@@ -5,7 +5,7 @@
 // Replaces triangular_solve_matrix (Eigen/src/Core/products/TriangularSolverMatrix.h:40-…)
 // behind EIGEN_BLAS_FUNC(trsm) (blas/level3_impl.h:78-178).  The reference walks small
 // panels with scalar substitution and updates the rest with its GEMM kernel
-// (TriangularSolverMatrix.h:166,183); here the diagonal blocks (128 x 128 or 256 x 256) are
+// (TriangularSolverMatrix.h:166,183); here the diagonal blocks (128 x 128 or 256 x 256, taken in pairs) are
 // inverted by a small kernel, a block solve is ONE in-place product with that inverse, and the
 // blocks are combined by recursive halving, whose updates are MFMA GEMMs with long reductions.
 // As in the reference the solve comes first and alpha is applied afterwards (level3_impl.h:163-175).
@@ -207,10 +207,13 @@ __global__ void __launch_bounds__(256) trtri_blocks(const T* __restrict__ A, int
 // only the block of A needs its extent: rows >= p_rows or columns >= p_cols of P (and likewise of Q) read as zero in the
 // LAST pair, which is the one a ragged matrix cuts short.  grid = ((NB / 32)^2, pairs); a workgroup owns a 32 x 32 tile
 // of C (thread: rows ti, ti + 16, columns 2 tj, 2 tj + 1) and walks k sixteen at a time, one chunk of loads ahead.
+// p_tri / q_tri: that operand is a triangle (1 lower, 2 upper; an inverse's image), and the part of the k range where it
+// is zero for the whole tile is not walked.
 template <typename T>
 __global__ void __launch_bounds__(256) trtri_pair_product(const T* __restrict__ P, int64_t ldp, int64_t sP, int p_rows, int p_cols,
                                                           const T* __restrict__ Q, int64_t ldq, int64_t sQ, int q_rows, int q_cols,
-                                                          T* __restrict__ C, int64_t ldc, int64_t sC, int nb, int negate) {
+                                                          T* __restrict__ C, int64_t ldc, int64_t sC, int nb, int negate,
+                                                          int p_tri, int q_tri, const int* __restrict__ pair_flags) {
   constexpr int kT = 32, kK = 16;
   __shared__ T s_a[kK][kT + 1];   // s_a[kk][i] = P(r0 + i, k0 + kk)
   __shared__ T s_b[kK][kT + 2];   // s_b[kk][j] = Q(k0 + kk, c0 + j)
@@ -237,15 +240,20 @@ __global__ void __launch_bounds__(256) trtri_pair_product(const T* __restrict__ 
     }
   };
   T acc[2][2] = {{zero_of<T>(), zero_of<T>()}, {zero_of<T>(), zero_of<T>()}};
-  fetch(0);
-  for (int k0 = 0; k0 < nb; k0 += kK) {
+  int k_begin = 0, k_end = nb;
+  if (p_tri == 1) k_end = min(k_end, r0 + kT);      // P(i, k) = 0 for k > i
+  if (p_tri == 2) k_begin = max(k_begin, r0);       // ... for k < i
+  if (q_tri == 1) k_begin = max(k_begin, c0);       // Q(k, j) = 0 for k < j
+  if (q_tri == 2) k_end = min(k_end, c0 + kT);      // ... for k > j
+  fetch(k_begin);
+  for (int k0 = k_begin; k0 < k_end; k0 += kK) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       s_a[ak + 8 * u][ai] = ra[u];
       s_b[bk][bj + 16 * u] = rb[u];
     }
     __syncthreads();
-    if (k0 + kK < nb) fetch(k0 + kK);
+    if (k0 + kK < k_end) fetch(k0 + kK);
 #pragma unroll
     for (int kk = 0; kk < kK; ++kk) {
       const T a0 = s_a[kk][ti], a1 = s_a[kk][ti + 16];
@@ -259,8 +267,9 @@ __global__ void __launch_bounds__(256) trtri_pair_product(const T* __restrict__ 
   for (int q = 0; q < 2; ++q)
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      const T v = acc[q][e];
-      C[(r0 + ti + 16 * q) + (int64_t)(c0 + 2 * tj + e) * ldc] = negate ? -v : v;
+      T v = negate ? -acc[q][e] : acc[q][e];
+      if (pair_flags && pair_flags[2 * pair]) v = zero_of<T>();   // a pair that is solved by substitution
+      C[(r0 + ti + 16 * q) + (int64_t)(c0 + 2 * tj + e) * ldc] = v;
     }
 }
 
@@ -275,9 +284,15 @@ __global__ void __launch_bounds__(256) trtri_decide(T* __restrict__ X, double li
   const int ldx = pairs ? 2 * NB : NB;
   __shared__ int s_subst;
   if (threadIdx.x == 0) {
-    const double mx = __longlong_as_double((long long)gmax[2 * blockIdx.x]);
-    const double ma = __longlong_as_double((long long)gmax[2 * blockIdx.x + 1]);   // (at least 1 for a unit diagonal)
-    s_subst = !(mx * ma <= limit);
+    auto grown = [&](int b) {
+      const double mx = __longlong_as_double((long long)gmax[2 * b]);
+      const double ma = __longlong_as_double((long long)gmax[2 * b + 1]);   // (at least 1 for a unit diagonal)
+      return !(mx * ma <= limit);
+    };
+    // In pairs the two blocks of a pair are decided together: one of them over the limit and the whole pair is solved
+    // by substitution (both images the identity, the off-diagonal block zero: trtri_pair_product looks at the flag).
+    const int partner = (int)blockIdx.x ^ 1;
+    s_subst = grown((int)blockIdx.x) || (pairs && partner < (int)gridDim.x && grown(partner));
     flags[blockIdx.x] = s_subst;
   }
   __syncthreads();
@@ -295,7 +310,8 @@ __global__ void __launch_bounds__(256) trtri_decide(T* __restrict__ X, double li
 //   right side  X op(A) = B  is  op(A)^T X^T = B^T  (a right-hand side is a row of B),
 //   an upper triangular M is a lower one with its indices reversed (`rev`).
 // inc_i: distance in B between consecutive unknowns of one right-hand side, inc_c: between
-// right-hand sides.
+// right-hand sides.  pb may be two blocks (a pair): the columns of M that a chunk needs pass through LDS in windows of
+// kLargeNB rows.
 constexpr int kSubChunk = 32;
 template <typename T>
 __global__ void __launch_bounds__(256) trsm_block_subst(const int* __restrict__ flag, const T* __restrict__ A, int64_t lda, int pb,
@@ -317,34 +333,39 @@ __global__ void __launch_bounds__(256) trsm_block_subst(const int* __restrict__ 
   auto b_at = [&](int i) -> T& { return b[(int64_t)(rev ? pb - 1 - i : i) * inc_i]; };
   for (int i0 = 0; i0 < pb; i0 += kSubChunk) {
     const int w = min(kSubChunk, pb - i0);
-    for (int idx = threadIdx.x; idx < kSubChunk * (pb - i0); idx += 256) {
-      const int kk = idx % kSubChunk, ii = idx / kSubChunk;
-      s_t[kk][ii] = (kk < w && ii >= kk) ? m_at(i0 + ii, i0 + kk) : (kk == ii ? One<T>::v() : zero_of<T>());
-    }
-    __syncthreads();
-    if (active) {
-      T x[kSubChunk];
-#pragma unroll
-      for (int ii = 0; ii < kSubChunk; ++ii) x[ii] = ii < w ? b_at(i0 + ii) : zero_of<T>();
-#pragma unroll
-      for (int ii = 0; ii < kSubChunk; ++ii) {
-        T v = x[ii];
-#pragma unroll
-        for (int kk = 0; kk < kSubChunk; ++kk)
-          if (kk < ii) v = v - s_t[kk][ii] * x[kk];
-        x[ii] = ii < w ? v / s_t[ii][ii] : zero_of<T>();
+    T x[kSubChunk];
+    for (int base = 0; base < pb - i0; base += kLargeNB) {   // rows [i0 + base, i0 + top) of the chunk's columns
+      const int top = min(base + kLargeNB, pb - i0);
+      for (int idx = threadIdx.x; idx < kSubChunk * (top - base); idx += 256) {
+        const int kk = idx % kSubChunk, ii = base + idx / kSubChunk;
+        s_t[kk][ii - base] = (kk < w && ii >= kk) ? m_at(i0 + ii, i0 + kk) : (kk == ii ? One<T>::v() : zero_of<T>());
       }
+      __syncthreads();
+      if (active) {
+        if (base == 0) {
 #pragma unroll
-      for (int ii = 0; ii < kSubChunk; ++ii)
-        if (ii < w) b_at(i0 + ii) = x[ii];
-      for (int i = i0 + kSubChunk; i < pb; ++i) {
-        T acc = zero_of<T>();
+          for (int ii = 0; ii < kSubChunk; ++ii) x[ii] = ii < w ? b_at(i0 + ii) : zero_of<T>();
 #pragma unroll
-        for (int kk = 0; kk < kSubChunk; ++kk) acc = acc + s_t[kk][i - i0] * x[kk];
-        b_at(i) = b_at(i) - acc;
+          for (int ii = 0; ii < kSubChunk; ++ii) {
+            T v = x[ii];
+#pragma unroll
+            for (int kk = 0; kk < kSubChunk; ++kk)
+              if (kk < ii) v = v - s_t[kk][ii] * x[kk];
+            x[ii] = ii < w ? v / s_t[ii][ii] : zero_of<T>();
+          }
+#pragma unroll
+          for (int ii = 0; ii < kSubChunk; ++ii)
+            if (ii < w) b_at(i0 + ii) = x[ii];
+        }
+        for (int i = i0 + max(base, kSubChunk); i < i0 + top; ++i) {
+          T acc = zero_of<T>();
+#pragma unroll
+          for (int kk = 0; kk < kSubChunk; ++kk) acc = acc + s_t[kk][i - i0 - base] * x[kk];
+          b_at(i) = b_at(i) - acc;
+        }
       }
+      __syncthreads();
     }
-    __syncthreads();
   }
 }
 
@@ -422,10 +443,11 @@ hipError_t trsm_device(int kind, bool left, bool upper, int op, bool unit, int64
   // blocks' inverses (-inv(T22) T21 inv(T11) off the diagonal, two small products for all pairs at once:
   // trtri_pair_product), and a leaf is one product with it where there were two leaves and the update between them --
   // three products of 256 x nrhs x 256, each a launch of few tiles with a cut reduction, become one of 512 x nrhs x 512.
-  // A block that is solved by substitution has the identity for its inverse, the pair's off-diagonal block then holds
-  // what is left of the update, and the substitutions run in front of the product (the block solved first) and behind
-  // it (the other one).  EIGAMD_TRSM_PAIRS=0: leaves of one block.
-  static const bool pairs_wanted = [] { const char* e = getenv("EIGAMD_TRSM_PAIRS"); return !(e && atoi(e) == 0); }();
+  // The growth of the two blocks' inverses is judged per pair: one of them over the limit and the pair's image is the
+  // identity and the whole pair is solved by substitution in front of the product.  EIGAMD_TRSM_PAIRS=0: leaves of one
+  // block.
+  const char* pairs_env = getenv("EIGAMD_TRSM_PAIRS");   // (read at every call: tests compare the two forms)
+  const bool pairs_wanted = !(pairs_env && atoi(pairs_env) == 0);
   const bool pairs = leaf_copy && pairs_wanted && nblk >= 2;
   const int64_t unit_blocks = pairs ? 2 : 1, kUnit = unit_blocks * kNB;
   const int64_t nunits = (nblk + unit_blocks - 1) / unit_blocks;
@@ -518,14 +540,14 @@ hipError_t trsm_device(int kind, bool left, bool upper, int op, bool unit, int64
       const TYPE* a = reinterpret_cast<const TYPE*>(A_off);                                                                        \
       if (!upper) { /* tmp = T21 inv(T11); X21 = -inv(T22) tmp */                                                                  \
         hipLaunchKernelGGL((trtri_pair_product<TYPE>), pgrid, dim3(256), 0, s, a, lda, s_a, last_hi, nb, img, kUnit, s_img, nb, nb, \
-                           t, kNB, s_tmp, nb, 0);                                                                                  \
+                           t, kNB, s_tmp, nb, 0, 0, 1, (const int*)nullptr);                                                                                  \
         hipLaunchKernelGGL((trtri_pair_product<TYPE>), pgrid, dim3(256), 0, s, img + o_hi, kUnit, s_img, nb, nb, t, kNB, s_tmp, nb, \
-                           nb, img + o_off, kUnit, s_img, nb, 1);                                                                  \
+                           nb, img + o_off, kUnit, s_img, nb, 1, 1, 0, flags);                                                           \
       } else {      /* tmp = T12 inv(T22); X12 = -inv(T11) tmp */                                                                  \
         hipLaunchKernelGGL((trtri_pair_product<TYPE>), pgrid, dim3(256), 0, s, a, lda, s_a, nb, last_hi, img + o_hi, kUnit, s_img,  \
-                           nb, nb, t, kNB, s_tmp, nb, 0);                                                                          \
+                           nb, nb, t, kNB, s_tmp, nb, 0, 0, 2, (const int*)nullptr);                                                                 \
         hipLaunchKernelGGL((trtri_pair_product<TYPE>), pgrid, dim3(256), 0, s, img, kUnit, s_img, nb, nb, t, kNB, s_tmp, nb, nb,    \
-                           img + o_off, kUnit, s_img, nb, 1);                                                                      \
+                           img + o_off, kUnit, s_img, nb, 1, 2, 0, flags);                                                              \
       }                                                                                                                            \
     }
     if (np > 0) {
@@ -586,16 +608,8 @@ hipError_t trsm_device(int kind, bool left, bool upper, int op, bool unit, int64
   rec.run = [&](int64_t j0, int64_t j1) -> hipError_t {
     if (j1 - j0 == 1) {
       const int64_t p0 = j0 * kUnit, pb = std::min<int64_t>(kUnit, ext - p0);
-      // the substitution form of the unit's blocks: the one solved first in front of the product, the other behind it
-      const bool two = pairs && pb > kNB;
-      const bool lo_first = left ? eff_lower : !eff_lower;
-      const int64_t b_first = unit_blocks * j0 + ((two && !lo_first) ? 1 : 0), b_second = unit_blocks * j0 + ((two && lo_first) ? 1 : 0);
-      auto block_subst = [&](int64_t b) { return subst(b, b * kNB, std::min<int64_t>(kNB, ext - b * kNB)); };
-      struct Behind {   // (the leaf returns from several places)
-        std::function<hipError_t()> f;
-        hipError_t run(hipError_t e) { return e != hipSuccess ? e : f(); }
-      } behind{[&]() -> hipError_t { return two ? block_subst(b_second) : hipSuccess; }};
-      TR_TRY(block_subst(b_first));
+      // the substitution form of the whole unit (one flag per pair: trtri_decide), a no-op unless flagged
+      TR_TRY(subst(unit_blocks * j0, p0, pb));
       if (leaf_copy) {  // the product into the scratch image (any tile may run it), then back
         // (Where the launcher cuts the leaf's reduction into pieces -- it does for most leaves: few tiles -- the pass
         // over the pieces writes B_j itself and there is nothing to copy: 16 us less per leaf, copy and the two gaps
@@ -604,14 +618,14 @@ hipError_t trsm_device(int kind, bool left, bool upper, int op, bool unit, int64
         bool direct = false;
         if (left) {
           TR_TRY(gemm(kind, op, OP_N, pb, n, pb, 1.0, inv(j0), kUnit, b_at(p0, 0), ldb, 0.0, leaf, pb, s, ws, ws ? ws_bytes : 0, b_at(p0, 0), ldb, &direct));
-          if (direct) return behind.run(hipSuccess);
-          return behind.run(hipMemcpy2DAsync(b_at(p0, 0), (size_t)ldb * es, leaf, (size_t)pb * es, (size_t)pb * es, (size_t)n,
-                                             hipMemcpyDeviceToDevice, s));
+          if (direct) return hipSuccess;
+          return hipMemcpy2DAsync(b_at(p0, 0), (size_t)ldb * es, leaf, (size_t)pb * es, (size_t)pb * es, (size_t)n,
+                                  hipMemcpyDeviceToDevice, s);
         }
         TR_TRY(gemm(kind, OP_N, op, m, pb, pb, 1.0, b_at(0, p0), ldb, inv(j0), kUnit, 0.0, leaf, m, s, ws, ws ? ws_bytes : 0, b_at(0, p0), ldb, &direct));
-        if (direct) return behind.run(hipSuccess);
-        return behind.run(hipMemcpy2DAsync(b_at(0, p0), (size_t)ldb * es, leaf, (size_t)m * es, (size_t)m * es, (size_t)pb,
-                                           hipMemcpyDeviceToDevice, s));
+        if (direct) return hipSuccess;
+        return hipMemcpy2DAsync(b_at(0, p0), (size_t)ldb * es, leaf, (size_t)m * es, (size_t)m * es, (size_t)pb,
+                                hipMemcpyDeviceToDevice, s);
       }
       // (in place: leaves of one block, kUnit == kNB)
       if (left)  // B_j <- op(inv_j) * B_j, in place (one tile row)

@@ -17,6 +17,7 @@ import oracle_lib as ol
 import eigen_amd
 from eigen_amd import _lib
 from eigen_amd.device import DeviceMatrix, trsm_dev
+from test_lu_config_gpu import env
 
 pytestmark = pytest.mark.gpu
 
@@ -84,6 +85,34 @@ def test_device_entry_vs_oracle_all_forms(kind):
                     assert np.abs(got - ref).max() <= 64 * ol.EPS[kind] * na * np.abs(ref).max(), (side, uplo, trans, diag)
                     # the triangle that must not be read still holds the rogue value
                     assert np.array_equal(da.to_numpy(), np.array(a))
+
+
+@pytest.mark.parametrize("kind", range(4))
+def test_leaves_of_two_blocks_all_forms_vs_leaves_of_one(kind):
+    """The leaves of the recursion are pairs of diagonal blocks whose inverse is put together from the blocks' inverses
+    (EIGAMD_TRSM_PAIRS=0: single blocks).  Every form over several pairs and a ragged last block (five blocks of 256 for
+    the real kinds, nine of 128 for the complex ones): the Netlib test ratio against the operands, and the two forms
+    against each other to the tolerance of the oracle comparisons."""
+    alpha = (0.7 - 0.9j) if kind >= 2 else 0.7
+    seed = 240
+    for side in "LR":
+        for uplo in "UL":
+            for trans in "NTC":
+                for diag in "NU":
+                    seed += 1
+                    m, n = (1100, 130) if side == "L" else (130, 1100)
+                    a, b = ol.trsm_operands(kind, side, uplo, diag, m, n, seed, pad=seed % 3)
+                    na = a.shape[0]
+                    out = []
+                    for pairs in (1, 0):
+                        da = DeviceMatrix.from_numpy(np.array(a), ld=na + seed % 3)
+                        db = DeviceMatrix.from_numpy(np.array(b), ld=m + 1)
+                        with env(EIGAMD_TRSM_PAIRS=pairs):
+                            trsm_dev(side, uplo, trans, diag, alpha, da, db)
+                        out.append(db.to_numpy())
+                    assert ol.trsm_residual_ratio(kind, side, uplo, trans, diag, alpha, a, b, out[0]) < RATIO_LIMIT, (side, uplo, trans, diag)
+                    assert ol.trsm_residual_ratio(kind, side, uplo, trans, diag, alpha, a, b, out[1]) < RATIO_LIMIT, (side, uplo, trans, diag)
+                    assert np.abs(out[0] - out[1]).max() <= 64 * ol.EPS[kind] * na * np.abs(out[1]).max(), (side, uplo, trans, diag)
 
 
 @pytest.mark.parametrize("kind,side,uplo,trans,diag", [(1, "L", "L", "N", "U"), (1, "R", "U", "T", "N"),
