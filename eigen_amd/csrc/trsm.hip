@@ -88,8 +88,9 @@ template <> struct One<Cplx<double>> { static __device__ Cplx<double> v() { retu
 // with rogue values) -- and its inverse is written as a full kNB x kNB matrix (zeros in the
 // other triangle) at X + b * kNB * kNB.  An upper triangle is inverted as the transpose of
 // a lower one.  grid = (kNB / kInvCols, number of blocks); a workgroup owns 32 columns of
-// one inverse in LDS and walks down the rows 32 at a time: first the part of the inner
-// products that needs finished rows only, then the 32 x 32 triangle on the diagonal.
+// one inverse in LDS and walks down the rows 32 at a time: the part of the inner products
+// that needs finished rows, times the inverse of the 32 x 32 triangle on the diagonal (those
+// inverses are formed first, all at once).
 // It also notes, per block, max|inv(T_b)| and max|T_b| over what it wrote and read (gmax[2 b], gmax[2 b + 1]: the bit
 // patterns of non-negative doubles order like the numbers, NaN above infinity, so an integer atomicMax folds them; the
 // words are zero on entry), which is all trtri_decide needs.
@@ -113,10 +114,10 @@ __global__ void __launch_bounds__(256) trtri_blocks(const T* __restrict__ A, int
                                                     T* __restrict__ X, unsigned long long* __restrict__ gmax, int pairs) {
   constexpr int kNB = NB;   // block extent of this instantiation
   const int ldx = pairs ? 2 * NB : NB;
+  constexpr int kSteps = NB / kInvCols;
   __shared__ T s_x[kInvCols][kNB + 1];
   __shared__ T s_acc[kInvCols][kInvCols + 1];
-  __shared__ T s_d[kInvCols][kInvCols + 1];  // s_d[k - i0][i - i0] = L(i, k) of the diagonal 32 x 32
-  __shared__ T s_diag[kInvCols];             // L(i, i) of those rows
+  __shared__ T s_dinv[kSteps][kInvCols][kInvCols + 1];  // [j][k][i]: first L(32 j + i, 32 j + k) (i >= k), then its inverse
   const int b0 = blockIdx.y * kNB;
   const int bs = min(kNB, na - b0);
   const T* Ab = A + b0 + (int64_t)b0 * lda;
@@ -124,10 +125,46 @@ __global__ void __launch_bounds__(256) trtri_blocks(const T* __restrict__ A, int
   auto at = [&](int i, int k) { return upper ? Ab[k + (int64_t)i * lda] : Ab[i + (int64_t)k * lda]; };  // i > k
   const int first = blockIdx.x * kInvCols;
   for (int idx = threadIdx.x; idx < kInvCols * kNB; idx += 256) s_x[idx / kNB][idx % kNB] = zero_of<T>();
+  // The 32 x 32 triangles on the diagonal, from this workgroup's columns on, all at once: loaded in one batch, then each
+  // inverted by half a wavefront (a column per lane, 32 steps of substitution) -- once, in parallel, instead of once per
+  // 32-row step with one half-wavefront at work.  Rows past the end of a ragged block count as rows of the identity.
+  for (int idx = threadIdx.x; idx < kSteps * kInvCols * kInvCols; idx += 256) {
+    const int j = idx / (kInvCols * kInvCols), kk = (idx / kInvCols) % kInvCols, ii = idx % kInvCols;
+    if (j < (int)blockIdx.x) continue;
+    const int r = j * kInvCols + ii, c = j * kInvCols + kk;
+    T v = zero_of<T>();
+    if (ii == kk) v = (unit || r >= bs) ? One<T>::v() : Ab[r + (int64_t)r * lda];
+    else if (ii > kk && r < bs) v = at(r, c);
+    s_dinv[j][kk][ii] = v;
+  }
+  __syncthreads();
+  {
+    const int j = threadIdx.x / kInvCols, c = threadIdx.x % kInvCols;
+    static_assert(kSteps <= 256 / kInvCols, "a half-wavefront per 32 x 32 triangle");
+    T x[kInvCols];
+    const bool mine = j < kSteps && j >= (int)blockIdx.x;
+    if (mine) {
+#pragma unroll
+      for (int ii = 0; ii < kInvCols; ++ii) {
+        T v = zero_of<T>();
+#pragma unroll
+        for (int kk = 0; kk < kInvCols; ++kk)
+          if (kk < ii) v = v + s_dinv[j][kk][ii] * x[kk];
+        if (ii < c) x[ii] = zero_of<T>();
+        else if (ii == c) x[ii] = One<T>::v() / s_dinv[j][ii][ii];
+        else x[ii] = -(v / s_dinv[j][ii][ii]);
+      }
+    }
+    __syncthreads();   // every lane has read its triangle
+    if (mine) {
+#pragma unroll
+      for (int ii = 0; ii < kInvCols; ++ii) s_dinv[j][c][ii] = x[ii];
+    }
+  }
   __syncthreads();
   const int il = threadIdx.x % kInvCols, cg = threadIdx.x / kInvCols;
   for (int i0 = first; i0 < bs; i0 += kInvCols) {
-    const int i = i0 + il;
+    const int i = i0 + il, j = i0 / kInvCols;
     T acc[4] = {zero_of<T>(), zero_of<T>(), zero_of<T>(), zero_of<T>()};
     if (i < bs) {
       for (int k = first; k < i0; k += 8) {
@@ -140,34 +177,22 @@ __global__ void __launch_bounds__(256) trtri_blocks(const T* __restrict__ A, int
           for (int q = 0; q < 4; ++q) acc[q] = acc[q] + l[u] * s_x[cg * 4 + q][k + u];
       }
     }
+    if (i0 == first) {   // the column block's own triangle: its inverse as it stands
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s_acc[cg * 4 + q][il] = acc[q];
-    for (int idx = threadIdx.x; idx < kInvCols * kInvCols; idx += 256) {
-      const int kk = idx / kInvCols, ii = idx % kInvCols;
-      s_d[kk][ii] = (i0 + ii < bs && ii > kk) ? at(i0 + ii, i0 + kk) : zero_of<T>();
-    }
-    if (threadIdx.x < kInvCols) {
-      const int r = i0 + threadIdx.x;
-      s_diag[threadIdx.x] = (unit || r >= bs) ? One<T>::v() : Ab[r + (int64_t)r * lda];
-    }
-    __syncthreads();
-    if (threadIdx.x < kInvCols) {
-      const int c = threadIdx.x, g = first + c;
-      T x[kInvCols];
+      for (int q = 0; q < 4; ++q) s_x[cg * 4 + q][i0 + il] = s_dinv[j][cg * 4 + q][il];
+    } else {             // rows below it: X(rows, c) = -inv(D) * (L(rows, above) X(above, c)), 32 x 32 x 32 by all threads
 #pragma unroll
-      for (int ii = 0; ii < kInvCols; ++ii) {
-        T v = s_acc[c][ii];
+      for (int q = 0; q < 4; ++q) s_acc[cg * 4 + q][il] = acc[q];
+      __syncthreads();
+      T v[4] = {zero_of<T>(), zero_of<T>(), zero_of<T>(), zero_of<T>()};
 #pragma unroll
-        for (int kk = 0; kk < kInvCols; ++kk)
-          if (kk < ii) v = v + s_d[kk][ii] * x[kk];
-        const int row = i0 + ii;
-        if (g >= bs || row >= bs || row < g) x[ii] = zero_of<T>();
-        else if (row == g) x[ii] = One<T>::v() / s_diag[ii];
-        else x[ii] = -(v / s_diag[ii]);
+      for (int kk = 0; kk < kInvCols; ++kk) {
+        const T d = s_dinv[j][kk][il];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = v[q] + d * s_acc[cg * 4 + q][kk];
       }
 #pragma unroll
-      for (int ii = 0; ii < kInvCols; ++ii)
-        if (i0 + ii < bs) s_x[c][i0 + ii] = x[ii];
+      for (int q = 0; q < 4; ++q) s_x[cg * 4 + q][i0 + il] = -v[q];
     }
     __syncthreads();
   }
@@ -206,7 +231,7 @@ __global__ void __launch_bounds__(256) trtri_blocks(const T* __restrict__ A, int
 // triangle likewise above the diagonal).  The images are whole NB x NB blocks with zeros where the triangle ends, so
 // only the block of A needs its extent: rows >= p_rows or columns >= p_cols of P (and likewise of Q) read as zero in the
 // LAST pair, which is the one a ragged matrix cuts short.  grid = ((NB / 32)^2, pairs); a workgroup owns a 32 x 32 tile
-// of C (thread: rows ti, ti + 16, columns 2 tj, 2 tj + 1) and walks k sixteen at a time, one chunk of loads ahead.
+// of C (thread: rows ti, ti + 16, columns 2 tj, 2 tj + 1) and walks k 32 at a time, one chunk of loads ahead.
 // p_tri / q_tri: that operand is a triangle (1 lower, 2 upper; an inverse's image), and the part of the k range where it
 // is zero for the whole tile is not walked.
 template <typename T>
@@ -214,7 +239,7 @@ __global__ void __launch_bounds__(256) trtri_pair_product(const T* __restrict__ 
                                                           const T* __restrict__ Q, int64_t ldq, int64_t sQ, int q_rows, int q_cols,
                                                           T* __restrict__ C, int64_t ldc, int64_t sC, int nb, int negate,
                                                           int p_tri, int q_tri, const int* __restrict__ pair_flags) {
-  constexpr int kT = 32, kK = 16;
+  constexpr int kT = 32, kK = 32, kPer = kT * kK / 256;
   __shared__ T s_a[kK][kT + 1];   // s_a[kk][i] = P(r0 + i, k0 + kk)
   __shared__ T s_b[kK][kT + 2];   // s_b[kk][j] = Q(k0 + kk, c0 + j)
   const int pair = blockIdx.y;
@@ -226,16 +251,17 @@ __global__ void __launch_bounds__(256) trtri_pair_product(const T* __restrict__ 
   Q += (int64_t)pair * sQ;
   C += (int64_t)pair * sC;
   const int t = threadIdx.x, ti = t % 16, tj = t / 16;
-  // loads of a chunk: P 32 x 16 (two per thread, consecutive threads down a column), Q 16 x 32 (two per thread)
-  const int ai = t % kT, ak = t / kT;          // and ak + 8
-  const int bk = t % kK, bj = t / kK;          // and bj + 16
-  T ra[2], rb[2];
+  // loads of a chunk: P 32 x kK and Q kK x 32, kPer each per thread, consecutive threads down a column
+  constexpr int kAStep = 256 / kT, kBStep = 256 / kK;
+  const int ai = t % kT, ak = t / kT;          // and ak + kAStep u
+  const int bk = t % kK, bj = t / kK;          // and bj + kBStep u
+  T ra[kPer], rb[kPer];
   auto fetch = [&](int k0) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int row = r0 + ai, col = k0 + ak + 8 * u;
+    for (int u = 0; u < kPer; ++u) {
+      const int row = r0 + ai, col = k0 + ak + kAStep * u;
       ra[u] = (row < pr && col < pc) ? P[row + (int64_t)col * ldp] : zero_of<T>();
-      const int qrow = k0 + bk, qcol = c0 + bj + 16 * u;
+      const int qrow = k0 + bk, qcol = c0 + bj + kBStep * u;
       rb[u] = (qrow < qr && qcol < qc) ? Q[qrow + (int64_t)qcol * ldq] : zero_of<T>();
     }
   };
@@ -248,9 +274,9 @@ __global__ void __launch_bounds__(256) trtri_pair_product(const T* __restrict__ 
   fetch(k_begin);
   for (int k0 = k_begin; k0 < k_end; k0 += kK) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      s_a[ak + 8 * u][ai] = ra[u];
-      s_b[bk][bj + 16 * u] = rb[u];
+    for (int u = 0; u < kPer; ++u) {
+      s_a[ak + kAStep * u][ai] = ra[u];
+      s_b[bk][bj + kBStep * u] = rb[u];
     }
     __syncthreads();
     if (k0 + kK < k_end) fetch(k0 + kK);
