@@ -159,26 +159,28 @@ def side_measurement(dtype, n, steps):
     return round(flops / best / 1e9, 2)
 
 
-def trsm_measurement(n):
-    """dtrsm('L','L','N','N') with an n x n triangle and n right-hand sides resident in HBM
-    (eigamd_trsm_dev); n^3 flop.  The block updates run on the GEMM kernel."""
+def trsm_measurement(n, letter="d", form="LLNN"):
+    """?trsm (side, uplo, trans, diag = `form`) with an n x n triangle and n right-hand sides resident in HBM
+    (eigamd_trsm_dev); n^3 flop (4 n^3 for the complex kinds).  The block updates run on the GEMM kernel."""
     import torch
     import eigen_amd
     from eigen_amd.device import DeviceMatrix, trsm_dev
-    a = DeviceMatrix(n, n, eigen_amd.F64).fill_uniform(5)
+    kind = {"s": eigen_amd.F32, "d": eigen_amd.F64, "c": eigen_amd.C32, "z": eigen_amd.C64}[letter]
+    a = DeviceMatrix(n, n, kind).fill_uniform(5)
     a.as_strided().mul_(2.0 / n)
     a.as_strided().diagonal().fill_(1.5)
-    b = DeviceMatrix(n, n, eigen_amd.F64)
+    b = DeviceMatrix(n, n, kind)
     best = 1e30
     for _ in range(3):
         b.fill_uniform(6)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        trsm_dev("L", "L", "N", "N", 1.0, a, b)
+        trsm_dev(form[0], form[1], form[2], form[3], 1.0, a, b)
         e1.record()
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1))
-    return {f"dtrsm_llnn_{n}_tflops": round(float(n) ** 3 / best / 1e9, 2)}
+    flops = (4.0 if letter in "cz" else 1.0) * float(n) ** 3
+    return {f"{letter}trsm_{form.lower()}_{n}_tflops": round(flops / best / 1e9, 2)}
 
 
 def syrk_measurement(n):
@@ -630,6 +632,9 @@ def main():
                 out["extra"].update(trsm_measurement(16384))
                 out["extra"].update(trsm_measurement(8192))
                 out["extra"].update(trsm_measurement(4096))
+                out["extra"].update(trsm_measurement(4096, "d", "RLNN"))
+                out["extra"].update(trsm_measurement(4096, "s"))
+                out["extra"].update(trsm_measurement(2048, "z"))
                 out["extra"].update(syrk_measurement(16384))
                 out["extra"].update(trmm_measurement(16384))
                 out["extra"].update(mixed_measurement(8192))
