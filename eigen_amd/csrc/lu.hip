@@ -1816,6 +1816,7 @@ template <typename T> struct Workspace {
   BaseCaseRule rule;
   int64_t wide_fixed, wide_t4, wide_t2;  // outer-step width rule of the look-ahead (outer_block)
   int64_t slice_cols, slice_min;  // the panel stream updates the last slice_cols columns itself while >= slice_min remain (0: off)
+  int64_t slice_from;             // ... in factorisations of at least this many columns beside the slice
   bool ramp;            // the first outer steps of the look-ahead are narrower than the rule's width
   int64_t split_min;    // the bulk update is dealt over two streams while at least this many columns remain (0: never)
   // Scratch of lu_swap_plan / lu_apply_plan and inverses of unit lower triangles (kPlanSpan^2
@@ -2172,7 +2173,7 @@ struct LuStreams {
 // EIGAMD_LU_WIDE fixes the width (a multiple of 256 up to kMaxSub * 256; 256 = one panel per
 // step); EIGAMD_LU_WIDE_T4 / _T2 move the thresholds.
 struct WidthRule {
-  int64_t fixed = 0, t4 = 20480, t2 = 16640;
+  int64_t fixed = 0, t4 = 20480, t2 = 12288;   // (t2 swept again with the faster base cases: 16384^2 114.0 -> 109.0 ms against 16640)
 };
 WidthRule read_width_rule() {  // (per factorisation: tests set the variables between calls)
   WidthRule v;
@@ -2216,7 +2217,7 @@ hipError_t blocked_lookahead(T* A, int64_t ld, int64_t rows, int64_t cols, int* 
   // (the step lasts as long as the trailing product).  They then update the LAST slice_cols columns of the
   // trailing matrix themselves -- the same chain on those columns, queued behind the step's panel -- and the
   // update streams leave those columns alone, from the first step until fewer than slice_min columns remain.
-  bool slicing = st.update && w.slice_cols > 0 && size - w.slice_cols >= w.slice_min;
+  bool slicing = st.update && w.slice_cols > 0 && size - w.slice_cols >= std::max(w.slice_from, w.slice_min);
   bool slice_recorded = false;
   int step = 0;
   // Width of step `i` when `remaining` columns are left.  The first steps ramp up (one panel, two panels,
@@ -2547,9 +2548,13 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
     w.split_min = 8192;
     w.ramp = true;
     w.slice_cols = 1024;
-    w.slice_min = 24576;
+    // (Swept again with the faster base cases: the slice pays from 25600 columns on -- at 24576 it costs 1 % -- and then
+    // until fewer than 20480 remain: 32768^2 489.5 -> 484 ms with the width rule below.)
+    w.slice_from = 24576;
+    w.slice_min = 20480;
     if (const char* e = getenv("EIGAMD_LU_SLICE")) w.slice_cols = atoll(e) / kPlanSpan * kPlanSpan;
-    if (const char* e = getenv("EIGAMD_LU_SLICE_MIN")) w.slice_min = atoll(e);
+    if (const char* e = getenv("EIGAMD_LU_SLICE_MIN")) w.slice_min = w.slice_from = atoll(e);
+    if (const char* e = getenv("EIGAMD_LU_SLICE_FROM")) w.slice_from = atoll(e);
     if (const char* e = getenv("EIGAMD_LU_RAMP")) w.ramp = atoi(e) != 0;
     if (const char* e = getenv("EIGAMD_LU_SPLIT_MIN")) w.split_min = atoll(e);
   }
