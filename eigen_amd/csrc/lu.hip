@@ -2596,7 +2596,7 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   // 126.9 -> 124.9 with 64 instead of 32 compute units; 20480^2 183 -> 188: there the trailing products need them).
   // (The streams are rebuilt when the split changes from one call to the next: a few hardware queues serve all the
   // streams of a process, and a second set kept alive would share them with the first.)
-  // (Measured again at the end of the third round, 32 / 64 units: 17408^2 130.0 / 122.0 ms, 18432^2 144.8 / 137.2, 20480^2 172.9 / 171.5,
+  // (Measured again with the base cases that read every candidate's row beside the poll, 32 / 64 units: 17408^2 130.0 / 122.0 ms, 18432^2 144.8 / 137.2, 20480^2 172.9 / 171.5,
   // 21504^2 194.4 / 190.8, 22528^2 212.4 / 211.8, 24576^2 252.5 / 258.0: 64 up to 22528 columns.)
   const bool panel_bound = std::min(m, n) <= 22528;
   LuStreams& streams = sc.streams;
