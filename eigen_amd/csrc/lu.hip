@@ -2591,9 +2591,9 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   LU_TRY(hipMemsetAsync(w.first_zero, 0xFF, sizeof(int), s));  // -1
   LU_TRY(hipMemsetAsync(w.nswaps, 0, sizeof(int), s));
   int per_cu = 0, total_cus = 0;
-  // Up to 16384 columns the factorisation waits for the panel chain from start to end, and a panel of up to 64
-  // workgroups runs faster with a compute unit per workgroup (8192^2 50.6 -> 48.5 ms, 12288^2 84.7 -> 80.0, 16384^2
-  // 126.9 -> 124.9 with 64 instead of 32 compute units; 20480^2 183 -> 188: there the trailing products need them).
+  // Up to some 20000 columns the factorisation waits for the panel chain most of the time, and a panel of up to 64
+  // workgroups runs faster with a compute unit per workgroup (first measured as 8192^2 50.6 -> 48.5 ms, 12288^2 84.7 -> 80.0,
+  // 16384^2 126.9 -> 124.9 with 64 instead of 32 compute units, and 20480^2 183 -> 188: the trailing products needed them).
   // (The streams are rebuilt when the split changes from one call to the next: a few hardware queues serve all the
   // streams of a process, and a second set kept alive would share them with the first.)
   // (Measured again with the base cases that read every candidate's row beside the poll, 32 / 64 units: 17408^2 130.0 / 122.0 ms, 18432^2 144.8 / 137.2, 20480^2 172.9 / 171.5,
