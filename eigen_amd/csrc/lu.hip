@@ -2175,8 +2175,11 @@ struct LuStreams {
 struct WidthRule {
   int64_t fixed = 0, t4 = 20480, t2 = 12288;   // (t2 swept again with the faster base cases: 16384^2 114.0 -> 109.0 ms against 16640)
 };
-WidthRule read_width_rule() {  // (per factorisation: tests set the variables between calls)
+// `single`: float, whose trailing products take half the time while its panels take the same: two-panel steps pay later
+// (16640: sgetrf 14336^2 73.9 ms against 75.4 with 12288; the complex kinds follow double: zgetrf 16384^2 294.8 -> 284.2).
+WidthRule read_width_rule(bool single) {  // (per factorisation: tests set the variables between calls)
   WidthRule v;
+  if (single) v.t2 = 16640;
   if (const char* e = getenv("EIGAMD_LU_WIDE")) v.fixed = atoll(e);
   if (const char* e = getenv("EIGAMD_LU_WIDE_T4")) v.t4 = atoll(e);
   if (const char* e = getenv("EIGAMD_LU_WIDE_T2")) v.t2 = atoll(e);
@@ -2543,7 +2546,7 @@ hipError_t getrf_device_t(int64_t m, int64_t n, T* A, int64_t ld, int* d_transp,
   w.rule = read_base_case_rule();
   if (!allow_fused) w.rule.fused = false;
   {
-    const WidthRule wr = read_width_rule();
+    const WidthRule wr = read_width_rule(std::is_same<T, float>::value);
     w.wide_fixed = wr.fixed; w.wide_t4 = wr.t4; w.wide_t2 = wr.t2;
     w.split_min = 8192;
     w.ramp = true;
